@@ -1,0 +1,169 @@
+/*
+ * paac_hip.h -- C-ABI of libpaac_hip.so: the MI355X (gfx950) hot path of PAAC.
+ *
+ * The reference (arjunchandra/paac) is pure Python/TensorFlow-1 and has no FFI; the entry points
+ * below are what a binding for its hot path would call, one per kernel family.  Each entry cites
+ * the reference code it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; paac_last_error() gives the message
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - the CALLER owns every tensor (device pointers + explicit dims); the library owns only the
+ *     opaque paac_ctx (activation/slab workspace) and paac_graph handles.
+ *   - every launch goes to the caller-supplied hipStream_t (passed as void*); no hidden host
+ *     synchronisation, no allocation after paac_create -> every entry is hipGraph-capturable.
+ *   - a ctx is not thread-safe; use one per process/GPU.
+ *   - all floating point is fp32 (the reference graph is fp32); the n-step return scan is fp64
+ *     like the reference's numpy buffers.
+ */
+#ifndef PAAC_HIP_H
+#define PAAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct paac_ctx paac_ctx;
+typedef struct paac_graph paac_graph;
+typedef void* paac_stream_t; /* hipStream_t */
+
+enum { PAAC_ARCH_NIPS = 0, PAAC_ARCH_NATURE = 1 };   /* networks.py:138-151 / :154-169 */
+enum { PAAC_CLIP_IGNORE = 0, PAAC_CLIP_GLOBAL = 1 }; /* actor_learner.py:51-59 ('local' is broken upstream) */
+
+#define PAAC_MAX_TENSORS 12
+#define PAAC_OBS_BYTES 28224 /* 84*84*4 */
+#define PAAC_RAW_H 210
+#define PAAC_RAW_W 160
+
+/* Flat parameter layout, TF variable-creation order (actor_learner.py:44 grads_and_vars order;
+ * pretrained checkpoints .index): conv1_w [8,8,4,C1], conv1_b, conv2_w, conv2_b, (conv3_w, conv3_b,)
+ * fcN_w [K,H], fcN_b, actor_w [H,A], actor_b, critic_w [H,1], critic_b.  Every tensor starts on a
+ * 4-float boundary; pad floats are zero and stay zero. */
+typedef struct {
+  int32_t num_tensors;
+  int64_t total;          /* floats, padded */
+  int64_t total_unpadded; /* the reference's parameter count P */
+  int64_t offset[PAAC_MAX_TENSORS];
+  int64_t size[PAAC_MAX_TENSORS];
+  int32_t rank[PAAC_MAX_TENSORS];
+  int32_t shape[PAAC_MAX_TENSORS][4];
+  char name[PAAC_MAX_TENSORS][32];
+} paac_layout;
+
+typedef struct {
+  int32_t device;      /* HIP device ordinal */
+  int32_t arch;        /* PAAC_ARCH_* */
+  int32_t num_actions; /* A, 2..32 */
+  int32_t max_batch;   /* largest batch any forward/backward will see (N*T for training) */
+} paac_cfg;
+
+const char* paac_last_error(void);
+int paac_version(void);
+
+int paac_param_layout(int arch, int num_actions, paac_layout* out);
+
+int paac_create(const paac_cfg* cfg, paac_ctx** out);
+int paac_destroy(paac_ctx* ctx);
+
+/* Policy/value inference: networks.py:100-169 + policy_v_network.py:24-37 (what
+ * paac.py:20-23 and :140-142 fetch).  states u8 [batch,84,84,4] NHWC.  Any of logits/probs/values
+ * may be NULL.  Activations stay in the ctx for a following paac_backward on the same batch. */
+int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch,
+                 float* logits, float* probs, float* values, paac_stream_t stream);
+
+/* Loss + gradients of policy_v_network.py:29-57 through the whole network (what
+ * optimizer.compute_gradients(loss), actor_learner.py:44, evaluates): runs the training forward
+ * on `states`, then backward.  actions = sampled action index per row (the one-hot's argmax,
+ * paac.py:27), y = critic target, adv = advantage, batch rows t-major (paac.py:151-154).
+ * grad: flat, padded layout.  loss_out (nullable, device float[4]) = {loss, actor, critic, mean entropy}. */
+int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
+                       const float* y, const float* adv, int batch, float entropy_beta,
+                       float* grad, float* loss_out, paac_stream_t stream);
+
+/* tf.clip_by_global_norm + RMSPropOptimizer.apply_gradients (actor_learner.py:31-34,56-59,70):
+ *   g <- grad * grad_scale           (grad_scale = 1/world_size after the sum all-reduce)
+ *   gn = sqrt(sum g^2); g <- g * clip_norm*min(1/gn, 1/clip_norm)  (mode GLOBAL)
+ *   ms += (g^2 - ms)(1-decay); mom = momentum*mom + lr*g/sqrt(ms+eps); var -= mom
+ * lr is read from device memory (*lr_dev) so the call can sit in a replayed graph.
+ * gnorm_out (nullable): device float receiving gn. */
+int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms, float* mom, int64_t n,
+                      const float* lr_dev, float decay, float momentum, float eps, float clip_norm,
+                      int clip_mode, float grad_scale, float* gnorm_out, paac_stream_t stream);
+
+/* actor_learner.py:119-123 + paac.py:127: *global_step += increment; *lr_out = f32(lr0 - step*lr0/anneal)
+ * (0 beyond anneal); evaluated in fp64 like the reference's Python float. */
+int paac_lr_step(int64_t* global_step_dev, int64_t increment, double initial_lr, int64_t lr_annealing_steps,
+                 float* lr_out_dev, paac_stream_t stream);
+
+/* paac.py:140-149: R = v_boot; for t = T-1..0: R = r_t + gamma*R*m_t; y_t = R; adv_t = R - V_t.
+ * fp64 scan, fp32 in/out.  rewards/masks/values/y/adv are [T,N] (t-major). */
+int paac_nstep_returns(const float* v_boot, const float* rewards, const float* masks, const float* values,
+                       int T, int N, double gamma, float* y, float* adv, paac_stream_t stream);
+
+/* paac.py:34-45 bit-exact: probs - float32.epsneg, then numpy legacy multinomial(1, p) per env in
+ * index order on ONE MT19937 stream.  mt_state: device uint32[625] = numpy key[624] + pos, advanced
+ * in place (import/export with np.random.get_state()/set_state()).  scratch: device, >=
+ * paac_sample_mt_scratch_bytes(N, A). */
+int64_t paac_sample_mt_scratch_bytes(int N, int A);
+int paac_sample_mt(const float* probs, int N, int A, uint32_t* mt_state, void* scratch, int32_t* actions,
+                   paac_stream_t stream);
+
+/* Throughput sampler (build's own spec, oracle/sampler.py:sample_philox): u = philox4x32-10
+ * (ctr = {env_offset+e, step lo, step hi, 0}; key = seed) with step = *step_base_dev + step_offset,
+ * action = inverse CDF on fp32 running sums.  The base lives in device memory and the offset is an
+ * immediate so a captured graph of T steps replays with a fresh base (paac_counter_add, once per cycle). */
+int paac_sample_philox(const float* probs, int N, int A, uint64_t seed, const uint64_t* step_base_dev,
+                       uint64_t step_offset, uint32_t env_offset, int32_t* actions, paac_stream_t stream);
+int paac_counter_add(uint64_t* counter_dev, uint64_t inc, paac_stream_t stream);
+
+/* emulator_runner.py:18-33 frame path on device: FramePool max over 2 raw frames
+ * (atari_emulator.py:72), PIL-nearest resize 210x160 -> 84x84 (:73), ObservationPool push + rotated
+ * read-out (environment.py:66-71).  raw: u8 [N,2,210,160] (gray) or [N,2,210,160,3] (rgb, converted with
+ * the ITU-R 601 fixed-point luma).  stack_in/stack_out: u8 [N,84,84,4] oldest..newest (may alias).
+ * push_mask (nullable): u8[N], 0 = copy the env's stack through unchanged.
+ * reset_mask (nullable): u8[N], !=0 = the three older channels are cleared before the push. */
+int paac_preprocess_stack(const uint8_t* raw, int is_rgb, int N, const uint8_t* stack_in, uint8_t* stack_out,
+                          const uint8_t* push_mask, const uint8_t* reset_mask, paac_stream_t stream);
+
+/* Device-resident synthetic environments (the metric's "synthetic 84x84x4 uint8 frames"; spec in
+ * paac_amd/synthetic.py, a BaseEnvironment plugin producing the same numbers on the host).
+ * One call replaces one Runners.update_environments()/wait_updated() round (runners.py:44-50) plus the
+ * per-env bookkeeping of paac.py:119-138 for N envs.  The frame id of the step is
+ * *step_base_dev + step_offset + 1 (id 0 is the reset frame):
+ *   stack_in -> stack_out (and stack_out2 if non-NULL); auto-reset on terminal like
+ *   emulator_runner.py:26-27; rewards_out f32[N] = clipped reward (actor_learner.py:95-101);
+ *   masks_out f32[N] = 1 - terminal; ep_reward f32[N] / ep_len i32[N] running episode totals;
+ *   finished: {i32 count; i32 pad; f32 reward[4096]; i32 len[4096]} ring of finished episodes.
+ * raw_scratch: NULL = path A (one new 84x84 plane per step); else u8 [N,2,210,160] = path B (two raw
+ * frames are generated there, then max + resize + stack via the preprocess kernel). */
+int paac_synth_reset(uint64_t seed, uint32_t env_offset, int N, uint8_t* stack_out, uint8_t* raw_scratch,
+                     paac_stream_t stream);
+int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* actions, uint32_t terminal_threshold,
+                    const uint64_t* step_base_dev, uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out,
+                    uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
+                    void* finished, uint8_t* raw_scratch, paac_stream_t stream);
+
+/* hipGraph helpers: capture every launch issued on `stream` between begin/end, replay with launch. */
+int paac_graph_begin(paac_stream_t stream);
+int paac_graph_end(paac_stream_t stream, paac_graph** out);
+int paac_graph_launch(paac_graph* g, paac_stream_t stream);
+int paac_graph_destroy(paac_graph* g);
+
+/* Test/debug: copy an internal activation to a caller device buffer (async on stream).
+ * what: 1..3 = conv outputs a1..a3 [batch,OH,OW,C], 4 = fc activations h [batch,H]. Returns element count. */
+int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream);
+
+/* Per-kernel timing hooks for bench.py's roofline object: when enabled, every kernel family launch is
+ * bracketed by hipEvents on the launch stream.  paac_prof_read synchronises the events and returns
+ * accumulated milliseconds + launch counts per family. */
+#define PAAC_PROF_FAMILIES 16
+int paac_prof_enable(paac_ctx* ctx, int on);
+int paac_prof_read(paac_ctx* ctx, double* ms_out, int64_t* count_out, int reset);
+const char* paac_prof_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAAC_HIP_H */

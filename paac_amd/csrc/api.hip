@@ -1,0 +1,303 @@
+// C-ABI: context, parameter layout, forward/backward entry points, hipGraph helpers, timing hooks.
+#include <stdarg.h>
+
+#include <new>
+
+#include "common.h"
+
+namespace paac {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+ArchSpec arch_spec(int arch) {
+  ArchSpec s;
+  memset(&s, 0, sizeof(s));
+  if (arch == PAAC_ARCH_NATURE) {
+    s.nconv = 3;
+    s.conv[0] = ConvSpec{84, 84, 4, 20, 20, 32, 8, 4};
+    s.conv[1] = ConvSpec{20, 20, 32, 9, 9, 64, 4, 2};
+    s.conv[2] = ConvSpec{9, 9, 64, 7, 7, 64, 3, 1};
+    s.flat = 3136;
+    s.fc = 512;
+  } else {
+    s.nconv = 2;
+    s.conv[0] = ConvSpec{84, 84, 4, 20, 20, 16, 8, 4};
+    s.conv[1] = ConvSpec{20, 20, 16, 9, 9, 32, 4, 2};
+    s.flat = 2592;
+    s.fc = 256;
+  }
+  return s;
+}
+
+int64_t wslab_floats_needed(int arch);
+int fc_splits_max();
+
+static const char* kFamilyNames[PAAC_PROF_FAMILIES] = {
+    "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "heads_fwd", "heads_bwd", "fc_wgrad", "fc_dgrad",
+    "conv_wgrad", "conv_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "sample", "env", "misc"};
+
+}  // namespace paac
+
+using namespace paac;
+
+struct paac_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+extern "C" {
+
+const char* paac_last_error(void) { return g_err; }
+int paac_version(void) { return 100; }
+
+int paac_param_layout(int arch, int num_actions, paac_layout* out) {
+  PAAC_REQUIRE(out, "paac_param_layout: null out");
+  PAAC_REQUIRE(arch == PAAC_ARCH_NIPS || arch == PAAC_ARCH_NATURE, "paac_param_layout: arch %d", arch);
+  PAAC_REQUIRE(num_actions >= 2 && num_actions <= 32, "paac_param_layout: num_actions %d not in [2,32]", num_actions);
+  memset(out, 0, sizeof(*out));
+  const ArchSpec s = arch_spec(arch);
+  int t = 0;
+  int64_t off = 0, unp = 0;
+  auto add = [&](const char* name, int rank, int d0, int d1, int d2, int d3) {
+    int64_t size = (int64_t)d0 * (rank > 1 ? d1 : 1) * (rank > 2 ? d2 : 1) * (rank > 3 ? d3 : 1);
+    snprintf(out->name[t], sizeof(out->name[t]), "%s", name);
+    out->rank[t] = rank;
+    out->shape[t][0] = d0; out->shape[t][1] = rank > 1 ? d1 : 0;
+    out->shape[t][2] = rank > 2 ? d2 : 0; out->shape[t][3] = rank > 3 ? d3 : 0;
+    out->offset[t] = off;
+    out->size[t] = size;
+    off += (size + 3) / 4 * 4;
+    unp += size;
+    ++t;
+  };
+  char nm[32];
+  for (int i = 0; i < s.nconv; ++i) {
+    snprintf(nm, sizeof(nm), "conv%d_weights", i + 1);
+    add(nm, 4, s.conv[i].k, s.conv[i].k, s.conv[i].cin, s.conv[i].cout);
+    snprintf(nm, sizeof(nm), "conv%d_biases", i + 1);
+    add(nm, 1, s.conv[i].cout, 0, 0, 0);
+  }
+  snprintf(nm, sizeof(nm), "fc%d_weights", s.nconv + 1);
+  add(nm, 2, s.flat, s.fc, 0, 0);
+  snprintf(nm, sizeof(nm), "fc%d_biases", s.nconv + 1);
+  add(nm, 1, s.fc, 0, 0, 0);
+  add("actor_output_weights", 2, s.fc, num_actions, 0, 0);
+  add("actor_output_biases", 1, num_actions, 0, 0, 0);
+  add("critic_output_weights", 2, s.fc, 1, 0, 0);
+  add("critic_output_biases", 1, 1, 0, 0, 0);
+  out->num_tensors = t;
+  out->total = off;
+  out->total_unpadded = unp;
+  return 0;
+}
+
+int paac_create(const paac_cfg* cfg, paac_ctx** out) {
+  PAAC_REQUIRE(cfg && out, "paac_create: null argument");
+  PAAC_REQUIRE(cfg->max_batch > 0, "paac_create: max_batch %d", cfg->max_batch);
+  int ndev = 0;
+  PAAC_CHECK_HIP(hipGetDeviceCount(&ndev));
+  PAAC_REQUIRE(ndev > 0, "paac_create: no HIP device visible (this library is MI355X-only; there is no CPU path)");
+  PAAC_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "paac_create: device %d of %d", cfg->device, ndev);
+  PAAC_CHECK_HIP(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  PAAC_CHECK_HIP(hipGetDeviceProperties(&prop, cfg->device));
+  PAAC_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+               "paac_create: device %d is %s; libpaac_hip is built for gfx950 (MI355X) only", cfg->device,
+               prop.gcnArchName);
+  paac_ctx* c = new (std::nothrow) paac_ctx;
+  PAAC_REQUIRE(c, "paac_create: out of host memory");
+  memset(c, 0, sizeof(*c));
+  c->cfg = *cfg;
+  if (paac_param_layout(cfg->arch, cfg->num_actions, &c->layout) != 0) {
+    delete c;
+    return -1;
+  }
+  c->spec = arch_spec(cfg->arch);
+  c->max_batch = cfg->max_batch;
+  const int64_t B = cfg->max_batch;
+  const int A = cfg->num_actions;
+  for (int i = 0; i < c->spec.nconv; ++i) {
+    const ConvSpec& cs = c->spec.conv[i];
+    const size_t bytes = (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float);
+    PAAC_CHECK_HIP(hipMalloc(&c->act[i], bytes));
+    PAAC_CHECK_HIP(hipMalloc(&c->dact[i], bytes));
+  }
+  c->fc_splits_max = fc_splits_max();
+  PAAC_CHECK_HIP(hipMalloc(&c->fc_slab, (size_t)c->fc_splits_max * B * c->spec.fc * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->h, (size_t)B * c->spec.fc * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->dh, (size_t)B * c->spec.fc * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->dhead, (size_t)B * (A + 1) * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->probs, (size_t)B * A * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->logits, (size_t)B * A * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->values, (size_t)B * sizeof(float)));
+  c->wslab_floats = wslab_floats_needed(cfg->arch);
+  PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->partials, 4096 * sizeof(float)));
+  PAAC_CHECK_HIP(hipMemset(c->partials, 0, 4096 * sizeof(float)));
+  c->ev_start = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
+  c->ev_stop = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
+  c->ev_family = new int[paac_ctx::PROF_MAX_EVENTS];
+  c->ev_count = 0;
+  c->prof_on = 0;
+  for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
+    c->ev_start[i] = nullptr;
+    c->ev_stop[i] = nullptr;
+  }
+  *out = c;
+  return 0;
+}
+
+int paac_destroy(paac_ctx* c) {
+  if (!c) return 0;
+  for (int i = 0; i < 3; ++i) {
+    if (c->act[i]) (void)hipFree(c->act[i]);
+    if (c->dact[i]) (void)hipFree(c->dact[i]);
+  }
+  float* bufs[] = {c->fc_slab, c->h, c->dh, c->dhead, c->probs, c->logits, c->values, c->wslab, c->partials};
+  for (float* b : bufs)
+    if (b) (void)hipFree(b);
+  for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
+    if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+    if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+  }
+  delete[] c->ev_start;
+  delete[] c->ev_stop;
+  delete[] c->ev_family;
+  delete c;
+  return 0;
+}
+
+int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* logits, float* probs,
+                 float* values, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states, "paac_forward: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_forward: batch %d outside (0, max_batch=%d]", batch,
+               ctx->max_batch);
+  const int rc = launch_forward(ctx, params, states, batch, true, logits, probs, values, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
+                       const float* adv, int batch, float entropy_beta, float* grad, float* loss_out,
+                       paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states && actions && y && adv && grad, "paac_loss_backward: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_loss_backward: batch %d outside (0, max_batch=%d]", batch,
+               ctx->max_batch);
+  int rc = launch_forward(ctx, params, states, batch, false, nullptr, nullptr, nullptr, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = launch_backward(ctx, params, states, actions, y, adv, batch, entropy_beta, grad, loss_out, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && out && batch > 0 && batch <= ctx->max_batch, "paac_debug_activation: bad arguments");
+  const float* src = nullptr;
+  int64_t n = 0;
+  if (what >= 1 && what <= ctx->spec.nconv) {
+    const ConvSpec& cs = ctx->spec.conv[what - 1];
+    src = ctx->act[what - 1];
+    n = (int64_t)batch * cs.oh * cs.ow * cs.cout;
+  } else if (what == 4) {
+    src = ctx->h;
+    n = (int64_t)batch * ctx->spec.fc;
+  } else if (what >= 11 && what <= 10 + ctx->spec.nconv) {
+    const ConvSpec& cs = ctx->spec.conv[what - 11];
+    src = ctx->dact[what - 11];
+    n = (int64_t)batch * cs.oh * cs.ow * cs.cout;
+  } else if (what == 14) {
+    src = ctx->dh;
+    n = (int64_t)batch * ctx->spec.fc;
+  } else {
+    set_error("paac_debug_activation: what=%d", what);
+    return -1;
+  }
+  PAAC_CHECK_HIP(hipMemcpyAsync(out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return n;
+}
+
+// ---- hipGraph helpers -------------------------------------------------------------------------
+int paac_graph_begin(paac_stream_t stream) {
+  PAAC_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+
+int paac_graph_end(paac_stream_t stream, paac_graph** out) {
+  PAAC_REQUIRE(out, "paac_graph_end: null out");
+  hipGraph_t g = nullptr;
+  PAAC_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    set_error("hipGraphInstantiate -> %s", hipGetErrorString(e));
+    return -2;
+  }
+  paac_graph* pg = new paac_graph{g, ex};
+  *out = pg;
+  return 0;
+}
+
+int paac_graph_launch(paac_graph* g, paac_stream_t stream) {
+  PAAC_REQUIRE(g, "paac_graph_launch: null graph");
+  PAAC_CHECK_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return 0;
+}
+
+int paac_graph_destroy(paac_graph* g) {
+  if (!g) return 0;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
+// ---- timing hooks -----------------------------------------------------------------------------
+int paac_prof_enable(paac_ctx* ctx, int on) {
+  PAAC_REQUIRE(ctx, "paac_prof_enable: null ctx");
+  if (on) {
+    for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
+      if (!ctx->ev_start[i]) PAAC_CHECK_HIP(hipEventCreate(&ctx->ev_start[i]));
+      if (!ctx->ev_stop[i]) PAAC_CHECK_HIP(hipEventCreate(&ctx->ev_stop[i]));
+    }
+  }
+  ctx->prof_on = on ? 1 : 0;
+  return 0;
+}
+
+int paac_prof_read(paac_ctx* ctx, double* ms_out, int64_t* count_out, int reset) {
+  PAAC_REQUIRE(ctx, "paac_prof_read: null ctx");
+  for (int i = 0; i < ctx->ev_count; ++i) {
+    PAAC_CHECK_HIP(hipEventSynchronize(ctx->ev_stop[i]));
+    float ms = 0.f;
+    PAAC_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+    ctx->prof_ms[ctx->ev_family[i]] += ms;
+    ctx->prof_n[ctx->ev_family[i]] += 1;
+  }
+  ctx->ev_count = 0;
+  for (int f = 0; f < PAAC_PROF_FAMILIES; ++f) {
+    if (ms_out) ms_out[f] = ctx->prof_ms[f];
+    if (count_out) count_out[f] = ctx->prof_n[f];
+    if (reset) {
+      ctx->prof_ms[f] = 0.0;
+      ctx->prof_n[f] = 0;
+    }
+  }
+  return 0;
+}
+
+const char* paac_prof_name(int family) {
+  if (family < 0 || family >= PAAC_PROF_FAMILIES) return "";
+  return kFamilyNames[family];
+}
+
+}  // extern "C"

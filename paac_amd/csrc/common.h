@@ -1,0 +1,112 @@
+// Internal definitions shared by the kernel translation units of libpaac_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/paac_hip.h"
+
+namespace paac {
+
+void set_error(const char* fmt, ...);
+
+#define PAAC_CHECK_HIP(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      paac::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return -2;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+#define PAAC_REQUIRE(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      paac::set_error(__VA_ARGS__);      \
+      return -1;                         \
+    }                                    \
+  } while (0)
+
+constexpr int OBS_H = 84, OBS_W = 84, OBS_C = 4;
+constexpr int OBS_PIX = OBS_H * OBS_W;  // 7056
+
+// Architecture description (networks.py:138-169).
+struct ConvSpec {
+  int ih, iw, cin, oh, ow, cout, k, stride;
+};
+struct ArchSpec {
+  int nconv;
+  ConvSpec conv[3];
+  int flat;  // fc input features
+  int fc;    // fc width H
+};
+ArchSpec arch_spec(int arch);
+
+// Kernel families for the timing hooks (paac_prof_*).
+enum Family {
+  F_CONV1_FWD = 0, F_CONV2_FWD, F_CONV3_FWD, F_FC_FWD, F_HEADS_FWD,
+  F_HEADS_BWD, F_FC_WGRAD, F_FC_DGRAD, F_CONV_WGRAD, F_CONV_DGRAD, F_CONV1_WGRAD,
+  F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_SAMPLE, F_ENV, F_MISC
+};
+static_assert(F_MISC + 1 == PAAC_PROF_FAMILIES, "family count");
+
+}  // namespace paac
+
+struct paac_ctx {
+  paac_cfg cfg;
+  paac::ArchSpec spec;
+  paac_layout layout;
+  int max_batch;
+  // activations (fp32, NHWC), sized for max_batch
+  float* act[3];   // conv outputs a1..a3
+  float* dact[3];  // gradients wrt conv outputs (post ReLU mask)
+  float* fc_slab;  // [FC_SPLITS_MAX][max_batch][H] split-K partials of the fc layer
+  float* h;        // [max_batch][H] fc activations
+  float* dh;       // [max_batch][H]
+  float* dhead;    // [max_batch][A+1] dlogits | dv
+  float* probs;    // [max_batch][A]  (kept for backward)
+  float* values;   // [max_batch]
+  float* logits;   // [max_batch][A]
+  float* wslab;    // wgrad split-K slabs (all layers, see slab_off)
+  int64_t wslab_floats;
+  float* partials; // sum-of-squares partials [1024] + loss partials
+  void* seg_table; // device table for grad finalize
+  int fc_splits_max;
+  // profiling hooks
+  int prof_on;
+  static constexpr int PROF_MAX_EVENTS = 8192;
+  hipEvent_t* ev_start;
+  hipEvent_t* ev_stop;
+  int* ev_family;
+  int ev_count;
+  double prof_ms[PAAC_PROF_FAMILIES];
+  int64_t prof_n[PAAC_PROF_FAMILIES];
+};
+
+namespace paac {
+
+// RAII-less helpers used by the launchers: record start/stop events when profiling is on.
+struct ProfScope {
+  paac_ctx* ctx;
+  hipStream_t s;
+  int idx;
+  ProfScope(paac_ctx* c, int family, hipStream_t stream) : ctx(c), s(stream), idx(-1) {
+    if (c && c->prof_on && c->ev_count < paac_ctx::PROF_MAX_EVENTS) {
+      idx = c->ev_count++;
+      c->ev_family[idx] = family;
+      (void)hipEventRecord(c->ev_start[idx], s);
+    }
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->ev_stop[idx], s);
+  }
+};
+
+// launchers implemented in the kernel translation units
+int launch_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, bool want_outputs,
+                   float* logits, float* probs, float* values, hipStream_t s);
+int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
+                    const float* adv, int batch, float beta, float* grad, float* loss_out, hipStream_t s);
+
+}  // namespace paac

@@ -1,0 +1,253 @@
+"""Thin, shape-checked Python wrappers over the C-ABI (include/paac_hip.h).
+
+torch is plumbing only (device memory + streams): every wrapper validates dtype / device / contiguity /
+extent on the host BEFORE the launch (a kernel that faults can take the whole node down), then hands raw
+device pointers to libpaac_hip.so on torch's current HIP stream.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+OBS_SHAPE = (84, 84, 4)
+RAW_H, RAW_W = 210, 160
+FINISHED_RING_BYTES = 8 + 4096 * 4 + 4096 * 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype, numel=None, name="tensor", optional=False):
+    if t is None:
+        if optional:
+            return ctypes.c_void_p(0)
+        raise ValueError("%s is required" % name)
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s must be a CUDA/HIP torch tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s: dtype %s, expected %s" % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if numel is not None and t.numel() < numel:
+        raise ValueError("%s: %d elements, need >= %d" % (name, t.numel(), numel))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Context(object):
+    """Owns one paac_ctx (activation workspace for one network on one GPU)."""
+
+    def __init__(self, arch, num_actions, max_batch, device_index=0):
+        self.lib = _lib.load()
+        self.arch = int(arch)
+        self.num_actions = int(num_actions)
+        self.max_batch = int(max_batch)
+        self.layout = _lib.param_layout(arch, num_actions)
+        cfg = _lib.Cfg(device=int(device_index), arch=self.arch, num_actions=self.num_actions, max_batch=self.max_batch)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.paac_create(ctypes.byref(cfg), ctypes.byref(h)), "paac_create")
+        self.handle = h
+        self.device = torch.device("cuda", device_index)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.paac_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- network ---------------------------------------------------------------------------------
+    def forward(self, params, states, logits=None, probs=None, values=None):
+        B = states.shape[0]
+        if tuple(states.shape[1:]) != OBS_SHAPE:
+            raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
+        if not (0 < B <= self.max_batch):
+            raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
+        A = self.num_actions
+        _lib.check(self.lib.paac_forward(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                         _ptr(states, torch.uint8, B * 28224, "states"), B,
+                                         _ptr(logits, torch.float32, B * A, "logits", True),
+                                         _ptr(probs, torch.float32, B * A, "probs", True),
+                                         _ptr(values, torch.float32, B, "values", True), _stream()), "paac_forward")
+
+    def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None):
+        B = states.shape[0]
+        if tuple(states.shape[1:]) != OBS_SHAPE:
+            raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
+        if not (0 < B <= self.max_batch):
+            raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
+        _lib.check(self.lib.paac_loss_backward(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                               _ptr(states, torch.uint8, B * 28224, "states"),
+                                               _ptr(actions, torch.int32, B, "actions"),
+                                               _ptr(y, torch.float32, B, "y"), _ptr(adv, torch.float32, B, "adv"), B,
+                                               float(entropy_beta),
+                                               _ptr(grad, torch.float32, self.layout["total"], "grad"),
+                                               _ptr(loss_out, torch.float32, 4, "loss_out", True), _stream()),
+                   "paac_loss_backward")
+
+    def clip_rmsprop(self, params, grad, ms, mom, lr_dev, decay, momentum, eps, clip_norm, clip_mode, grad_scale=1.0,
+                     gnorm_out=None):
+        n = self.layout["total"]
+        _lib.check(self.lib.paac_clip_rmsprop(self.handle, _ptr(params, torch.float32, n, "params"),
+                                              _ptr(grad, torch.float32, n, "grad"), _ptr(ms, torch.float32, n, "ms"),
+                                              _ptr(mom, torch.float32, n, "mom"), n,
+                                              _ptr(lr_dev, torch.float32, 1, "lr_dev"), float(decay), float(momentum),
+                                              float(eps), float(clip_norm), int(clip_mode), float(grad_scale),
+                                              _ptr(gnorm_out, torch.float32, 1, "gnorm_out", True), _stream()),
+                   "paac_clip_rmsprop")
+
+    def debug_activation(self, what, batch):
+        spec = {1: None}
+        out = torch.empty(batch * 20 * 20 * 64, dtype=torch.float32, device=self.device)
+        n = self.lib.paac_debug_activation(self.handle, int(what), int(batch), ctypes.c_void_p(out.data_ptr()), _stream())
+        _lib.check(n, "paac_debug_activation")
+        return out[:n].clone()
+
+    # -- timing hooks ----------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        _lib.check(self.lib.paac_prof_enable(self.handle, 1 if on else 0), "paac_prof_enable")
+
+    def prof_read(self, reset=True):
+        ms = (ctypes.c_double * _lib.PROF_FAMILIES)()
+        cnt = (ctypes.c_int64 * _lib.PROF_FAMILIES)()
+        _lib.check(self.lib.paac_prof_read(self.handle, ms, cnt, 1 if reset else 0), "paac_prof_read")
+        return {self.lib.paac_prof_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(_lib.PROF_FAMILIES)}
+
+
+# -- context-free entry points -------------------------------------------------------------------
+def lr_step(global_step_dev, increment, initial_lr, lr_annealing_steps, lr_out_dev):
+    lib = _lib.load()
+    _lib.check(lib.paac_lr_step(_ptr(global_step_dev, torch.int64, 1, "global_step"), int(increment), float(initial_lr),
+                                int(lr_annealing_steps), _ptr(lr_out_dev, torch.float32, 1, "lr_out"), _stream()),
+               "paac_lr_step")
+
+
+def nstep_returns(v_boot, rewards, masks, values, gamma, y, adv):
+    T, N = rewards.shape
+    lib = _lib.load()
+    _lib.check(lib.paac_nstep_returns(_ptr(v_boot, torch.float32, N, "v_boot"), _ptr(rewards, torch.float32, T * N, "rewards"),
+                                      _ptr(masks, torch.float32, T * N, "masks"), _ptr(values, torch.float32, T * N, "values"),
+                                      T, N, float(gamma), _ptr(y, torch.float32, T * N, "y"),
+                                      _ptr(adv, torch.float32, T * N, "adv"), _stream()), "paac_nstep_returns")
+
+
+def sample_mt_scratch(N, A, device):
+    nbytes = _lib.load().paac_sample_mt_scratch_bytes(int(N), int(A))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+
+def sample_mt(probs, mt_state, scratch, actions):
+    N, A = probs.shape
+    lib = _lib.load()
+    need = lib.paac_sample_mt_scratch_bytes(int(N), int(A))
+    if scratch.numel() * scratch.element_size() < need:
+        raise ValueError("sample_mt scratch too small: %d < %d bytes" % (scratch.numel() * scratch.element_size(), need))
+    _lib.check(lib.paac_sample_mt(_ptr(probs, torch.float32, N * A, "probs"), N, A,
+                                  _ptr(mt_state, torch.int32, 625, "mt_state"), ctypes.c_void_p(scratch.data_ptr()),
+                                  _ptr(actions, torch.int32, N, "actions"), _stream()), "paac_sample_mt")
+
+
+def mt_state_from_numpy(state, device):
+    """np.random.get_state() tuple -> device int32[625] (key + pos)."""
+    assert state[0] == "MT19937"
+    arr = np.concatenate([np.asarray(state[1], dtype=np.uint32), np.array([state[2]], dtype=np.uint32)])
+    return torch.from_numpy(arr.view(np.int32).copy()).to(device)
+
+
+def mt_state_to_numpy(mt_state):
+    arr = mt_state.detach().cpu().numpy().view(np.uint32)
+    return ("MT19937", arr[:624].copy(), int(arr[624]), 0, 0.0)
+
+
+def sample_philox(probs, seed, step_base_dev, step_offset, env_offset, actions):
+    N, A = probs.shape
+    lib = _lib.load()
+    _lib.check(lib.paac_sample_philox(_ptr(probs, torch.float32, N * A, "probs"), N, A, int(seed),
+                                      _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
+                                      int(env_offset), _ptr(actions, torch.int32, N, "actions"), _stream()),
+               "paac_sample_philox")
+
+
+def counter_add(counter_dev, inc):
+    _lib.check(_lib.load().paac_counter_add(_ptr(counter_dev, torch.int64, 1, "counter"), int(inc), _stream()),
+               "paac_counter_add")
+
+
+def preprocess_stack(raw, stack_in, stack_out, push_mask=None, reset_mask=None):
+    N = raw.shape[0]
+    if tuple(raw.shape) == (N, 2, RAW_H, RAW_W):
+        rgb = 0
+    elif tuple(raw.shape) == (N, 2, RAW_H, RAW_W, 3):
+        rgb = 1
+    else:
+        raise ValueError("raw must be [N,2,210,160] or [N,2,210,160,3] uint8, got %s" % (tuple(raw.shape),))
+    for nm, t in (("stack_in", stack_in), ("stack_out", stack_out)):
+        if tuple(t.shape) != (N,) + OBS_SHAPE:
+            raise ValueError("%s must be [%d,84,84,4], got %s" % (nm, N, tuple(t.shape)))
+    _lib.check(_lib.load().paac_preprocess_stack(_ptr(raw, torch.uint8, None, "raw"), rgb, N,
+                                                 _ptr(stack_in, torch.uint8, N * 28224, "stack_in"),
+                                                 _ptr(stack_out, torch.uint8, N * 28224, "stack_out"),
+                                                 _ptr(push_mask, torch.uint8, N, "push_mask", True),
+                                                 _ptr(reset_mask, torch.uint8, N, "reset_mask", True), _stream()),
+               "paac_preprocess_stack")
+
+
+def synth_reset(seed, env_offset, stack_out, raw_scratch=None):
+    N = stack_out.shape[0]
+    if tuple(stack_out.shape) != (N,) + OBS_SHAPE:
+        raise ValueError("stack_out must be [N,84,84,4]")
+    _lib.check(_lib.load().paac_synth_reset(int(seed), int(env_offset), N, _ptr(stack_out, torch.uint8, N * 28224, "stack_out"),
+                                            _ptr(raw_scratch, torch.uint8, N * 2 * RAW_H * RAW_W, "raw_scratch", True),
+                                            _stream()), "paac_synth_reset")
+
+
+def synth_step(seed, env_offset, actions, terminal_threshold, step_base_dev, step_offset, stack_in, stack_out,
+               rewards_out, masks_out, ep_reward, ep_len, finished=None, stack_out2=None, raw_scratch=None):
+    N = actions.shape[0]
+    for nm, t in (("stack_in", stack_in), ("stack_out", stack_out)):
+        if tuple(t.shape) != (N,) + OBS_SHAPE:
+            raise ValueError("%s must be [%d,84,84,4], got %s" % (nm, N, tuple(t.shape)))
+    if finished is not None and finished.numel() * finished.element_size() < FINISHED_RING_BYTES:
+        raise ValueError("finished ring too small")
+    _lib.check(_lib.load().paac_synth_step(int(seed), int(env_offset), N, _ptr(actions, torch.int32, N, "actions"),
+                                           int(terminal_threshold), _ptr(step_base_dev, torch.int64, 1, "step_base", True),
+                                           int(step_offset), _ptr(stack_in, torch.uint8, N * 28224, "stack_in"),
+                                           _ptr(stack_out, torch.uint8, N * 28224, "stack_out"),
+                                           _ptr(stack_out2, torch.uint8, N * 28224, "stack_out2", True),
+                                           _ptr(rewards_out, torch.float32, N, "rewards_out"),
+                                           _ptr(masks_out, torch.float32, N, "masks_out"),
+                                           _ptr(ep_reward, torch.float32, N, "ep_reward"),
+                                           _ptr(ep_len, torch.int32, N, "ep_len"),
+                                           ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0),
+                                           _ptr(raw_scratch, torch.uint8, N * 2 * RAW_H * RAW_W, "raw_scratch", True),
+                                           _stream()), "paac_synth_step")
+
+
+class Graph(object):
+    """hipGraph captured from the launches issued on torch's current stream between begin() and end()."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.handle = None
+
+    def begin(self):
+        _lib.check(self.lib.paac_graph_begin(_stream()), "paac_graph_begin")
+
+    def end(self):
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.paac_graph_end(_stream(), ctypes.byref(h)), "paac_graph_end")
+        self.handle = h
+
+    def launch(self):
+        _lib.check(self.lib.paac_graph_launch(self.handle, _stream()), "paac_graph_launch")
+
+    def close(self):
+        if self.handle:
+            self.lib.paac_graph_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,130 @@
+"""Network plugin surface (mirrors reference networks.py:100-169).
+
+In the reference a Network is a TensorFlow graph fragment; here it is a DESCRIPTION (architecture id, flat
+parameter layout) plus the flat fp32 parameter buffer in HBM.  The arithmetic -- u8->f32 * (1/255)
+(networks.py:115), VALID NHWC x HWIO convs + bias + ReLU (:12-21), HWC flatten (:6-9), fc + ReLU (:49-60),
+softmax head (:84-89) -- is executed by libpaac_hip.so (csrc/net.hip).  The attribute names the learner and
+test.py touch (`input_ph`, `output`, `init(checkpoint_folder, saver, session)`) are kept.
+
+New architectures: the reference lets users subclass Network and set `self.output`; here an architecture is a
+compiled kernel chain, so adding one means adding its geometry to csrc/net.hip (NatureNet / NipsNet) and an
+entry in ARCH_IDS.
+"""
+import glob
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class Placeholder(object):
+    """Stand-in for a tf.placeholder / tf.Tensor handle: identity-compared key of feed_dict / fetches."""
+
+    def __init__(self, name, dtype=None, shape=None):
+        self.name, self.dtype, self.shape = name, dtype, shape
+
+    def __repr__(self):
+        return "<paac_amd.%s>" % self.name
+
+
+ARCH_IDS = {"NIPS": _lib.ARCH_NIPS, "NATURE": _lib.ARCH_NATURE}
+
+
+def resolve_device(device):
+    """'/gpu:K' (reference flag syntax, train.py:80) or 'cuda:K' -> torch.device.  There is no CPU path."""
+    d = str(device)
+    if "cpu" in d:
+        raise RuntimeError("paac_amd is MI355X-only: device %r is not supported (the CPU restatement of the "
+                           "reference path lives in oracle/ and is test infrastructure)" % device)
+    idx = int(d.rsplit(":", 1)[1]) if ":" in d else 0
+    return torch.device("cuda", idx)
+
+
+class Network(object):
+    ARCH = None
+
+    def __init__(self, conf):
+        self.name = conf['name']
+        self.num_actions = conf['num_actions']
+        self.clip_norm = conf['clip_norm']
+        self.clip_norm_type = conf['clip_norm_type']
+        self.device = conf['device']
+        self.loss_scaling = 5.0                                   # networks.py:112
+        self.input_ph = Placeholder('input', np.uint8, [None, 84, 84, 4])
+        self.selected_action_ph = Placeholder('selected_action', np.float32, [None, self.num_actions])
+        self.input = Placeholder('input_scaled')                  # cast(u8) * (1/255), fused into conv1
+        self.output = None
+        self.layout = None
+        self.params = None
+
+    # -- parameters --------------------------------------------------------------------------------
+    def _allocate(self):
+        if self.ARCH is None:
+            raise NotImplementedError("Network must be subclassed (networks.py:117)")
+        self.arch_id = ARCH_IDS[self.ARCH]
+        self.layout = _lib.param_layout(self.arch_id, self.num_actions)
+        self.torch_device = resolve_device(self.device)
+        self.params = torch.zeros(self.layout["total"], dtype=torch.float32, device=self.torch_device)
+
+    def tensor_names(self):
+        return [t["name"] for t in self.layout["tensors"]]
+
+    def set_parameters(self, named):
+        """named: {tensor name: array of the reference shape} (conv HWIO, fc [in,out])."""
+        host = np.zeros(self.layout["total"], dtype=np.float32)
+        for t in self.layout["tensors"]:
+            a = np.asarray(named[t["name"]], dtype=np.float32)
+            if a.shape != t["shape"]:
+                raise ValueError("%s: shape %s, expected %s" % (t["name"], a.shape, t["shape"]))
+            host[t["offset"]:t["offset"] + t["size"]] = a.reshape(-1)
+        self.params.copy_(torch.from_numpy(host))
+
+    def get_parameters(self, flat=None):
+        host = (self.params if flat is None else flat).detach().cpu().numpy()
+        return {t["name"]: host[t["offset"]:t["offset"] + t["size"]].reshape(t["shape"]).copy()
+                for t in self.layout["tensors"]}
+
+    def initialize(self, rng=None):
+        """'torch' init of the reference (networks.py:24-46,63-81): U(-d, d), d = 1/sqrt(fan_in) for W and b."""
+        rng = np.random.RandomState() if rng is None else rng
+        named = {}
+        fan_in = 1
+        for t in self.layout["tensors"]:
+            if t["name"].endswith("weights"):
+                fan_in = int(np.prod(t["shape"][:-1]))
+            d = 1.0 / np.sqrt(fan_in)
+            named[t["name"]] = rng.uniform(-d, d, size=t["shape"]).astype(np.float32)
+        self.set_parameters(named)
+
+    def init(self, checkpoint_folder, saver, session):
+        """networks.py:122-135: restore the latest checkpoint if there is one (step parsed from the file
+        name after the last '-'), else initialise all variables.  Returns last_saving_step."""
+        last_saving_step = 0
+        path = saver.latest_checkpoint(checkpoint_folder) if saver is not None else None
+        if path is None:
+            logging.info('Initializing all variables')
+            self.initialize()
+        else:
+            logging.info('Restoring network variables from previous run')
+            saver.restore(session, path)
+            last_saving_step = int(path[path.rindex('-') + 1:].split('.')[0])
+        return last_saving_step
+
+
+class NIPSNetwork(Network):
+    ARCH = "NIPS"       # conv(16,8,4) -> conv(32,4,2) -> fc 256   (networks.py:138-151)
+
+    def __init__(self, conf):
+        super(NIPSNetwork, self).__init__(conf)
+        self.output = Placeholder('fc3')
+
+
+class NatureNetwork(Network):
+    ARCH = "NATURE"     # conv(32,8,4) -> conv(64,4,2) -> conv(64,3,1) -> fc 512   (networks.py:154-169)
+
+    def __init__(self, conf):
+        super(NatureNetwork, self).__init__(conf)
+        self.output = Placeholder('fc4')

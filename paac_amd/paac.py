@@ -1,0 +1,315 @@
+"""PAAC learner (mirrors reference paac.py:13-187).
+
+`PAACLearner(network_creator, environment_creator, args)`, `.train()`, `.cleanup()` and the static
+`choose_next_actions(network, num_actions, states, session)` keep the reference's signatures.
+
+train() has two executions of the SAME cycle (paac.py:99-183):
+  * device-resident (environments with a device twin): T x [policy forward -> sample -> env step] ->
+    bootstrap forward -> n-step returns -> forward/backward -> (RCCL all-reduce) -> clip + RMSProp, every
+    stage a HIP kernel, the whole cycle replayed as a hipGraph; nothing crosses PCIe per step.
+  * host environments (any BaseEnvironment plugin): the reference's loop, with session.run replaced by
+    kernel launches and the numpy sampler/return maths by their HIP twins; actions are bit-identical to
+    the reference's numpy sampler on the same np.random seed (paac_sample_mt).
+"""
+import logging
+import time
+
+import numpy as np
+import torch
+
+from . import hip_ops
+from .actor_learner import ActorLearner
+from .runners import EmulatorRunner, Runners
+
+
+class DeviceRollout(object):
+    """Device-resident rollout/update cycle for N local environments x T steps."""
+
+    def __init__(self, learner, env_spec, sampler="philox", sampler_seed=42, env_offset=0, use_graph=True,
+                 total_envs=None):
+        L = learner
+        self.L = L
+        dev = L.torch_device
+        N, T, A = L.emulator_counts, L.max_local_steps, L.num_actions
+        self.N, self.T, self.A = N, T, A
+        self.total_envs = total_envs if total_envs is not None else N * L._world()
+        self.env_spec = env_spec
+        self.env_offset = int(env_offset)
+        self.sampler = sampler
+        self.sampler_seed = int(sampler_seed)
+        self.use_graph = use_graph
+        self.states = torch.zeros((T + 1, N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        self.actions = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        self.values = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.masks = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.probs = torch.zeros((N, A), dtype=torch.float32, device=dev)
+        self.v_boot = torch.zeros((N,), dtype=torch.float32, device=dev)
+        self.y = torch.zeros((T * N,), dtype=torch.float32, device=dev)
+        self.adv = torch.zeros((T * N,), dtype=torch.float32, device=dev)
+        self.ep_reward = torch.zeros((N,), dtype=torch.float32, device=dev)
+        self.ep_len = torch.zeros((N,), dtype=torch.int32, device=dev)
+        self.finished = torch.zeros((hip_ops.FINISHED_RING_BYTES // 4,), dtype=torch.int32, device=dev)
+        self.tick = torch.zeros((1,), dtype=torch.int64, device=dev)          # env steps taken (per env)
+        self.global_step_dev = torch.full((1,), int(L.global_step), dtype=torch.int64, device=dev)
+        self.raw = None
+        if env_spec.get("raw_frames"):
+            self.raw = torch.zeros((N, 2, hip_ops.RAW_H, hip_ops.RAW_W), dtype=torch.uint8, device=dev)
+        if sampler == "numpy":
+            self.mt_state = hip_ops.mt_state_from_numpy(np.random.get_state(), dev)
+            self.mt_scratch = hip_ops.sample_mt_scratch(N, A, dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph_a = None
+        self.graph_b = None
+        hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
+        self.states[T].copy_(self.states[0])
+        torch.cuda.synchronize(dev)
+
+    # -- stages --------------------------------------------------------------------------------------
+    def _rollout_and_backward(self):
+        L, T, N = self.L, self.T, self.N
+        params = L.network.params
+        self.states[0].copy_(self.states[T])                      # carry the last observation over
+        for t in range(T):
+            L.ctx.forward(params, self.states[t], probs=self.probs, values=self.values[t])
+            if self.sampler == "numpy":
+                hip_ops.sample_mt(self.probs, self.mt_state, self.mt_scratch, self.actions[t])
+            else:
+                hip_ops.sample_philox(self.probs, self.sampler_seed, self.tick, t, self.env_offset, self.actions[t])
+            hip_ops.synth_step(self.env_spec["seed"], self.env_offset, self.actions[t],
+                               self.env_spec["terminal_threshold"], self.tick, t, self.states[t], self.states[t + 1],
+                               self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
+                               raw_scratch=self.raw)
+        L.ctx.forward(params, self.states[T], values=self.v_boot)                     # paac.py:140-142
+        hip_ops.nstep_returns(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv)
+        L.ctx.loss_backward(params, self.states[:T].view(T * N, 84, 84, 4), self.actions.view(-1), self.y, self.adv,
+                            L.entropy_beta, L.grad, L.loss_dev)
+
+    def _update(self):
+        L = self.L
+        hip_ops.lr_step(self.global_step_dev, self.total_envs * self.T, L.initial_lr, L.lr_annealing_steps, L.lr_dev)
+        hip_ops.counter_add(self.tick, self.T)
+        L.ctx.clip_rmsprop(L.network.params, L.grad, L.rms, L.mom, L.lr_dev, L.alpha, L.momentum, L.e, L.clip_norm,
+                           L.clip_mode, L._grad_scale(), L.gnorm_dev)
+
+    def capture(self):
+        """Capture the cycle into hipGraphs (two halves when a gradient all-reduce sits between them)."""
+        with torch.cuda.stream(self.stream):
+            world = self.L._world()
+            ga = hip_ops.Graph()
+            ga.begin()
+            self._rollout_and_backward()
+            if world == 1:
+                self._update()
+            ga.end()
+            self.graph_a = ga
+            if world > 1:
+                gb = hip_ops.Graph()
+                gb.begin()
+                self._update()
+                gb.end()
+                self.graph_b = gb
+
+    def run_cycle(self):
+        with torch.cuda.stream(self.stream):
+            if self.use_graph:
+                if self.graph_a is None:
+                    self.capture()
+                self.graph_a.launch()
+                if self.graph_b is not None:
+                    self.L._allreduce_grad()
+                    self.graph_b.launch()
+            else:
+                self._rollout_and_backward()
+                self.L._allreduce_grad()
+                self._update()
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def finished_episodes(self):
+        """Drain the device ring of finished episodes -> list of (reward, length)."""
+        host = self.finished.cpu().numpy()
+        count = int(host[0])
+        n = min(count, 4096)
+        rewards = host[2:2 + 4096].view(np.float32)
+        lens = host[2 + 4096:2 + 8192]
+        idx = [(count - n + i) & 4095 for i in range(n)]
+        return count, [(float(rewards[i]), int(lens[i])) for i in idx]
+
+    def close(self):
+        for g in (self.graph_a, self.graph_b):
+            if g is not None:
+                g.close()
+        self.graph_a = self.graph_b = None
+
+
+class PAACLearner(ActorLearner):
+    def __init__(self, network_creator, environment_creator, args):
+        super(PAACLearner, self).__init__(network_creator, environment_creator, args)
+        self.workers = args.emulator_workers
+        self.args = args
+        self.runners = None
+        self.rollout = None
+
+    @staticmethod
+    def choose_next_actions(network, num_actions, states, session):
+        network_output_v, network_output_pi = session.run(
+            [network.output_layer_v, network.output_layer_pi],
+            feed_dict={network.input_ph: states})
+        action_indices = PAACLearner._sample_policy_action(network_output_pi)
+        new_actions = np.eye(num_actions)[action_indices]
+        return new_actions, network_output_v, network_output_pi
+
+    @staticmethod
+    def _sample_policy_action(probs):
+        """paac.py:34-45 executed by paac_sample_mt on the global np.random MT19937 stream: the stream is
+        uploaded, advanced on the device exactly as numpy's multinomial would advance it, and written back."""
+        probs = np.ascontiguousarray(np.asarray(probs, dtype=np.float32))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        p = torch.from_numpy(probs).to(dev)
+        state = hip_ops.mt_state_from_numpy(np.random.get_state(), dev)
+        scratch = hip_ops.sample_mt_scratch(p.shape[0], p.shape[1], dev)
+        actions = torch.empty((p.shape[0],), dtype=torch.int32, device=dev)
+        hip_ops.sample_mt(p, state, scratch, actions)
+        np.random.set_state(hip_ops.mt_state_to_numpy(state))
+        return [int(a) for a in actions.cpu().numpy()]
+
+    def _use_device_envs(self):
+        spec = getattr(self.environment_creator, "device_env_spec", None)
+        return spec is not None and not getattr(self.args, "host_environments", False)
+
+    def train(self):
+        """Main actor learner loop for parallel advantage actor critic learning (paac.py:59-183)."""
+        self.global_step = self.init_network()
+        logging.debug("Starting training at Step {}".format(self.global_step))
+        if self._use_device_envs():
+            self._train_device()
+        else:
+            self._train_host()
+        self.cleanup()
+
+    # -- device-resident loop ------------------------------------------------------------------------
+    def _train_device(self):
+        args = self.args
+        world = self._world()
+        rank = 0
+        if world > 1:
+            import torch.distributed as dist
+            rank = dist.get_rank()
+        N, T = self.emulator_counts, self.max_local_steps
+        self.rollout = DeviceRollout(self, self.environment_creator.device_env_spec,
+                                     sampler=getattr(args, "sampler", "philox"),
+                                     sampler_seed=getattr(args, "sampler_seed", 42), env_offset=rank * N,
+                                     use_graph=getattr(args, "use_graph", True))
+        counter = 0
+        global_step_start = self.global_step
+        start_time = time.time()
+        log_every = 2048 / self.emulator_counts            # paac.py:172 (float division, as upstream)
+        steps_per_cycle = N * T * world
+        while self.global_step < self.max_global_steps:
+            loop_start_time = time.time()
+            self.rollout.run_cycle()
+            self.global_step += steps_per_cycle
+            counter += 1
+            if counter % log_every == 0:
+                self.rollout.synchronize()
+                curr_time = time.time()
+                _, eps = self.rollout.finished_episodes()
+                last_ten = 0.0 if len(eps) < 1 else np.mean([r for r, _ in eps[-10:]])
+                logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), last 10 rewards avg {}"
+                             .format(self.global_step, steps_per_cycle / (curr_time - loop_start_time),
+                                     (self.global_step - global_step_start) / (curr_time - start_time), last_ten))
+            self.save_vars()
+        self.rollout.synchronize()
+
+    # -- host-environment loop (the reference's structure, kernels instead of session.run) ------------
+    def _train_host(self):
+        dev = self.torch_device
+        N, T, A = self.emulator_counts, self.max_local_steps, self.num_actions
+        counter = 0
+        global_step_start = self.global_step
+        total_rewards = []
+        variables = [(np.asarray([emulator.get_initial_state() for emulator in self.emulators], dtype=np.uint8)),
+                     (np.zeros(N, dtype=np.float32)),
+                     (np.asarray([False] * N, dtype=np.float32)),
+                     (np.zeros((N, A), dtype=np.float32))]
+        self.runners = Runners(EmulatorRunner, self.emulators, self.workers, variables)
+        self.runners.start()
+        shared_states, shared_rewards, shared_episode_over, shared_actions = self.runners.get_shared_variables()
+
+        emulator_steps = [0] * N
+        total_episode_rewards = N * [0]
+        d_states = torch.zeros((T, N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        d_cur = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        d_actions = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        d_values = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        d_rewards = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        d_masks = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        d_probs = torch.zeros((N, A), dtype=torch.float32, device=dev)
+        d_vboot = torch.zeros((N,), dtype=torch.float32, device=dev)
+        d_y = torch.zeros((T * N,), dtype=torch.float32, device=dev)
+        d_adv = torch.zeros((T * N,), dtype=torch.float32, device=dev)
+        mt_state = hip_ops.mt_state_from_numpy(np.random.get_state(), dev)
+        mt_scratch = hip_ops.sample_mt_scratch(N, A, dev)
+        rewards = np.zeros((T, N), dtype=np.float32)
+        masks = np.zeros((T, N), dtype=np.float32)
+        params = self.network.params
+        start_time = time.time()
+        self.last_feed = None
+
+        while self.global_step < self.max_global_steps:
+            loop_start_time = time.time()
+            for t in range(T):
+                d_states[t].copy_(torch.from_numpy(shared_states))
+                self.ctx.forward(params, d_states[t], probs=d_probs, values=d_values[t])
+                hip_ops.sample_mt(d_probs, mt_state, mt_scratch, d_actions[t])
+                idx = d_actions[t].cpu().numpy()
+                shared_actions[...] = np.eye(A, dtype=np.float32)[idx]
+                self.runners.update_environments()
+                self.runners.wait_updated()
+                masks[t] = 1.0 - shared_episode_over.astype(np.float32)
+                for e, (actual_reward, episode_over) in enumerate(zip(shared_rewards, shared_episode_over)):
+                    total_episode_rewards[e] += actual_reward
+                    rewards[t, e] = self.rescale_reward(actual_reward)
+                    emulator_steps[e] += 1
+                    self.global_step += 1
+                    if episode_over:
+                        total_rewards.append(total_episode_rewards[e])
+                        total_episode_rewards[e] = 0
+                        emulator_steps[e] = 0
+            d_cur.copy_(torch.from_numpy(shared_states))
+            self.ctx.forward(params, d_cur, values=d_vboot)
+            d_rewards.copy_(torch.from_numpy(rewards))
+            d_masks.copy_(torch.from_numpy(masks))
+            hip_ops.nstep_returns(d_vboot, d_rewards, d_masks, d_values, self.gamma, d_y, d_adv)
+            lr = self.get_lr()
+            self.lr_dev.fill_(float(np.float32(lr)))
+            self.ctx.loss_backward(params, d_states.view(T * N, 84, 84, 4), d_actions.view(-1), d_y, d_adv,
+                                   self.entropy_beta, self.grad, self.loss_dev)
+            self._allreduce_grad()
+            self.ctx.clip_rmsprop(params, self.grad, self.rms, self.mom, self.lr_dev, self.alpha, self.momentum, self.e,
+                                  self.clip_norm, self.clip_mode, self._grad_scale(), self.gnorm_dev)
+            if getattr(self.args, "record_feeds", False):
+                self.last_feed = dict(states=d_states.view(T * N, 84, 84, 4).cpu().numpy(), y=d_y.cpu().numpy(),
+                                      adv=d_adv.cpu().numpy(), actions=d_actions.view(-1).cpu().numpy(), lr=lr,
+                                      values=d_values.cpu().numpy(), global_step=self.global_step)
+                if getattr(self.args, "feed_callback", None):
+                    self.args.feed_callback(self.last_feed)
+            counter += 1
+            if counter % (2048 / self.emulator_counts) == 0:
+                curr_time = time.time()
+                last_ten = 0.0 if len(total_rewards) < 1 else np.mean(total_rewards[-10:])
+                logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), last 10 rewards avg {}"
+                             .format(self.global_step, T * N / (curr_time - loop_start_time),
+                                     (self.global_step - global_step_start) / (curr_time - start_time), last_ten))
+            self.save_vars()
+        np.random.set_state(hip_ops.mt_state_to_numpy(mt_state))
+
+    def cleanup(self):
+        super(PAACLearner, self).cleanup()
+        if self.runners is not None:
+            self.runners.stop()
+            self.runners = None
+        if self.rollout is not None:
+            self.rollout.close()

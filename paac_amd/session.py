@@ -1,0 +1,90 @@
+"""`Session`: the object passed where the reference passes a tf.Session (paac.py:18-29, test.py:77).
+
+It understands exactly the fetch/feed patterns of the hot path and dispatches them to the HIP library:
+  run([net.output_layer_v, net.output_layer_pi], {net.input_ph: states})          paac.py:20-23
+  run(net.output_layer_v, {net.input_ph: states})                                  paac.py:140-142
+  run([learner.train_step, ...], {input_ph, critic_target_ph, selected_action_ph,  paac.py:157-165
+                                  adv_actor_ph, learner.learning_rate})
+Host numpy in, host numpy out (the reference's contract); PAACLearner.train() itself uses the fused
+device-resident path and never goes through here per step.
+"""
+import numpy as np
+import torch
+
+from . import hip_ops
+
+
+class Saver(object):
+    """Stand-in for tf.train.Saver over .npz files whose keys are the reference's variable names
+    ('<scope>/<tensor name>', optimizer slots '<...>/OptimizerVariables' and '<...>/OptimizerVariables_1',
+    actor_learner.py:26-27,79-82)."""
+
+    def __init__(self, get_arrays, set_arrays, max_to_keep=5):
+        self.get_arrays, self.set_arrays, self.max_to_keep = get_arrays, set_arrays, max_to_keep
+
+    @staticmethod
+    def latest_checkpoint(folder):
+        import glob
+        import os
+        files = glob.glob(os.path.join(folder, "-*.npz"))
+        if not files:
+            return None
+        return max(files, key=lambda p: int(p[p.rindex('-') + 1:].split('.')[0]))
+
+    def save(self, session, folder, global_step):
+        import glob
+        import os
+        path = os.path.join(folder, "-%d.npz" % int(global_step))
+        np.savez(path, **self.get_arrays())
+        old = sorted(glob.glob(os.path.join(folder, "-*.npz")), key=lambda p: int(p[p.rindex('-') + 1:].split('.')[0]))
+        for p in old[:-self.max_to_keep]:
+            os.remove(p)
+        return path
+
+    def restore(self, session, path):
+        with np.load(path, allow_pickle=False) as z:
+            self.set_arrays({k: z[k] for k in z.files})
+
+
+class Session(object):
+    def __init__(self, network, ctx, learner=None):
+        self.network = network
+        self.ctx = ctx
+        self.learner = learner
+        self.device = network.torch_device
+        self.closed = False
+
+    def _states(self, feed_dict):
+        s = np.ascontiguousarray(np.asarray(feed_dict[self.network.input_ph]).astype(np.uint8))
+        return torch.from_numpy(s).to(self.device)
+
+    def run(self, fetches, feed_dict=None):
+        if self.closed:
+            raise RuntimeError("Session is closed")
+        net = self.network
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        if self.learner is not None and self.learner.train_step in flist:
+            self.learner._train_step_from_feed(feed_dict)
+            out = [None for _ in flist]
+            return out[0] if single else out
+        states = self._states(feed_dict)
+        B = states.shape[0]
+        A = net.num_actions
+        probs = torch.empty((B, A), dtype=torch.float32, device=self.device)
+        values = torch.empty((B,), dtype=torch.float32, device=self.device)
+        for i in range(0, B, self.ctx.max_batch):            # evaluation batches may exceed the training batch
+            j = min(B, i + self.ctx.max_batch)
+            self.ctx.forward(net.params, states[i:j], probs=probs[i:j], values=values[i:j])
+        res = []
+        for f in flist:
+            if f is net.output_layer_v:
+                res.append(values.cpu().numpy())
+            elif f is net.output_layer_pi:
+                res.append(probs.cpu().numpy())
+            else:
+                raise ValueError("Session.run: unsupported fetch %r" % (f,))
+        return res[0] if single else res
+
+    def close(self):
+        self.closed = True

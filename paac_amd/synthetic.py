@@ -1,0 +1,125 @@
+"""Synthetic environments: the metric's "synthetic 84x84x4 uint8 frames".
+
+This is the SPEC of the synthetic environment family; the same numbers are produced
+  * on the host by `SyntheticEnvironment` (a BaseEnvironment plugin, numpy), and
+  * on the device by paac_synth_reset / paac_synth_step (csrc/misc.hip), N envs per launch.
+The reference has no synthetic environment (it drives ALE, atari_emulator.py); this one exists so the hot
+path can be measured and parity-tested without an emulator.  Call pattern mirrors AtariEmulator:
+get_initial_state() / next(one_hot) -> (obs, reward, terminal)  (atari_emulator.py:88-106).
+
+Spec (all arithmetic uint32, wrapping):
+  lowbias32(x): x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16
+  key(seed, env, id) = lowbias32( lowbias32(seed_lo ^ lowbias32(env + 0x9E3779B9)) ^ seed_hi
+                                  ^ lowbias32(id_lo*0x85EBCA6B + id_hi + 0x7F4A7C15) )
+  word(key, w)       = lowbias32(key + w*0x9E3779B9 + 0x165667B1)        (4 little-endian bytes = 4 pixels)
+  frame id           = number of next() calls so far (id 0 = the frame of the very first initial state)
+  path A plane       pixel (y,x) = byte (x&3) of word(key, y*21 + (x>>2))
+  path B raw frames  frame f, pixel (ry,rx) = byte (rx&3) of word(key ^ 0x5bd1e995, f*8400 + ry*40 + (rx>>2));
+                     plane = nearest-resize(max(frame0, frame1))   (atari_emulator.py:69-75)
+  reward             = [-2,0,0,1,3][(lowbias32(key ^ 0xA511E9B3) % 5 + action) % 5]   (unclipped)
+  terminal           = lowbias32(key ^ 0x3C6EF372) < terminal_threshold
+  observation        = previous stack shifted by one channel with the new plane as channel 3; the initial
+                       state (construction and after a terminal) is [0, 0, 0, current plane].
+"""
+import numpy as np
+
+from .environment import BaseEnvironment
+
+M32 = np.uint64(0xFFFFFFFF)
+REWARD_TABLE = np.array([-2.0, 0.0, 0.0, 1.0, 3.0], dtype=np.float32)
+
+
+def lowbias32(x):
+    x = np.asarray(x, dtype=np.uint64) & M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7feb352d)) & M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846ca68b)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def synth_key(seed, env, frame_id):
+    seed = int(seed)
+    frame_id = int(frame_id)
+    k = lowbias32(np.uint64(seed & 0xFFFFFFFF) ^ lowbias32(np.uint64((int(env) + 0x9E3779B9) & 0xFFFFFFFF)))
+    idh = lowbias32(np.uint64(((frame_id & 0xFFFFFFFF) * 0x85EBCA6B + (frame_id >> 32) + 0x7F4A7C15) & 0xFFFFFFFF))
+    return int(lowbias32(k ^ np.uint64((seed >> 32) & 0xFFFFFFFF) ^ idh))
+
+
+def synth_words(key, w):
+    w = np.asarray(w, dtype=np.uint64)
+    return lowbias32((np.uint64(key) + w * np.uint64(0x9E3779B9) + np.uint64(0x165667B1)) & M32).astype(np.uint32)
+
+
+def terminal_threshold(p):
+    return int(min(max(p, 0.0), 1.0) * 4294967296.0) & 0xFFFFFFFF if p < 1.0 else 0xFFFFFFFF
+
+
+def plane_a(key):
+    words = synth_words(key, np.arange(84 * 21))
+    return words.astype("<u4").view(np.uint8).reshape(84, 84)
+
+
+def raw_frames_b(key):
+    words = synth_words(key ^ 0x5bd1e995, np.arange(2 * 210 * 40))
+    return words.astype("<u4").view(np.uint8).reshape(2, 210, 160)
+
+
+def _pil_nearest_lut(src, dst=84):
+    scale = src / float(dst)
+    xo = 0.0 + scale * 0.5
+    lut = np.empty(dst, dtype=np.int64)
+    for x in range(dst):
+        lut[x] = int(xo)
+        xo += scale
+    return lut
+
+
+ROW_LUT = _pil_nearest_lut(210)
+COL_LUT = _pil_nearest_lut(160)
+
+
+class SyntheticEnvironment(BaseEnvironment):
+    def __init__(self, actor_id, num_actions, seed=0, terminal_p=0.01, raw_frames=False):
+        self.actor_id = int(actor_id)
+        self.num_actions = int(num_actions)
+        self.seed = int(seed)
+        self.threshold = terminal_threshold(terminal_p)
+        self.raw_frames = bool(raw_frames)
+        self.frame_id = 0
+        self.stack = np.zeros((84, 84, 4), dtype=np.uint8)
+        self.plane = None
+
+    def _plane(self, key):
+        if self.raw_frames:
+            fr = raw_frames_b(key)
+            return np.maximum(fr[0], fr[1])[ROW_LUT][:, COL_LUT]
+        return plane_a(key)
+
+    def get_initial_state(self):
+        if self.plane is None:
+            self.plane = self._plane(synth_key(self.seed, self.actor_id, 0))
+        self.stack = np.zeros((84, 84, 4), dtype=np.uint8)
+        self.stack[..., 3] = self.plane
+        return np.copy(self.stack)
+
+    def next(self, action):
+        a = int(np.argmax(action))
+        self.frame_id += 1
+        key = synth_key(self.seed, self.actor_id, self.frame_id)
+        self.plane = self._plane(key)
+        new = np.empty_like(self.stack)
+        new[..., :3] = self.stack[..., 1:]
+        new[..., 3] = self.plane
+        self.stack = new
+        hr = int(lowbias32(np.uint64(key ^ 0xA511E9B3)))
+        reward = float(REWARD_TABLE[(hr % 5 + a) % 5])
+        terminal = int(lowbias32(np.uint64(key ^ 0x3C6EF372))) < self.threshold
+        return np.copy(self.stack), reward, bool(terminal)
+
+    def get_legal_actions(self):
+        return np.arange(self.num_actions)
+
+    def get_noop(self):
+        return [1.0, 0.0]

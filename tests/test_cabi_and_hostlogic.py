@@ -1,0 +1,146 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/paac_hip.h declares, the
+parameter layout agrees with the oracle, host-side mirrors behave like the reference classes, and the
+product never imports the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from paac_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "paac_hip.h")).read()
+    declared = set(re.findall(r"\b(paac_[a-z0-9_]+)\s*\(", hdr)) - {"paac_ctx", "paac_graph", "paac_cfg", "paac_layout"}
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libpaac_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTED_SYMBOLS), (declared ^ set(_lib.EXPORTED_SYMBOLS))
+    assert _lib.load().paac_version() >= 100
+
+
+def test_param_layout_matches_oracle_order():
+    from oracle import network as onet
+    from paac_amd import _lib
+    for arch, aid in (("NIPS", 0), ("NATURE", 1)):
+        for A in (4, 6, 18):
+            lay = _lib.param_layout(aid, A)
+            want = onet.param_shapes(arch, A)
+            assert [(t["name"], t["shape"]) for t in lay["tensors"]] == [(n, tuple(s)) for n, s in want]
+            assert lay["total_unpadded"] == onet.num_params(arch, A)
+            assert all(t["offset"] % 4 == 0 for t in lay["tensors"]) and lay["total"] % 4 == 0
+    with pytest.raises(_lib.PaacHipError):
+        _lib.param_layout(1, 1)
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from paac_amd import _lib
+    cfg = _lib.Cfg(device=0, arch=1, num_actions=4, max_batch=8)
+    h = ctypes.c_void_p()
+    rc = _lib.load().paac_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc < 0 and _lib.load().paac_last_error()
+
+
+def test_product_never_imports_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "paac_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), "%s imports the oracle" % f
+    code = "import sys; import paac_amd.train; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_pools_match_oracle_restatement():
+    from oracle import preprocess as opre
+    from paac_amd.environment import FramePool, ObservationPool
+    rs = np.random.RandomState(0)
+    fp = FramePool(np.empty((2, 210, 160), dtype=np.uint8), opre.max_resize)
+    op = ObservationPool(np.zeros((84, 84, 4), dtype=np.uint8))
+    fo, oo = opre.FramePoolOracle(), opre.ObservationPoolOracle()
+    for _ in range(7):
+        fr = rs.randint(0, 256, (210, 160)).astype(np.uint8)
+        fp.new_frame(fr)
+        fo.new_frame(fr)
+        fr = rs.randint(0, 256, (210, 160)).astype(np.uint8)
+        fp.new_frame(fr)
+        fo.new_frame(fr)
+        op.new_observation(fp.get_processed_frame())
+        oo.new_observation(fo.get_processed_frame())
+        assert np.array_equal(op.get_pooled_observations(), oo.get_pooled_observations())
+
+
+def test_synthetic_spec_luts_and_stats():
+    from oracle import preprocess as opre
+    from paac_amd import synthetic
+    assert np.array_equal(synthetic.ROW_LUT, opre.ROW_LUT) and np.array_equal(synthetic.COL_LUT, opre.COL_LUT)
+    env = synthetic.SyntheticEnvironment(0, 4, seed=3, terminal_p=0.1)
+    s = env.get_initial_state()
+    assert s.shape == (84, 84, 4) and s.dtype == np.uint8 and s[..., :3].max() == 0
+    terms, rewards = 0, []
+    for i in range(2000):
+        o, r, t = env.next(np.eye(4)[i % 4])
+        terms += t
+        rewards.append(r)
+        if t:
+            o = env.get_initial_state()
+    assert 120 < terms < 290                      # p = 0.1
+    assert set(rewards) <= {-2.0, 0.0, 1.0, 3.0}
+    assert 100 < np.mean(o[..., 3]) < 155
+
+
+def test_arg_parser_matches_reference_flags():
+    from paac_amd import train
+    a = train.get_arg_parser().parse_args([])
+    want = dict(game="pong", device="/gpu:0", rom_path="./atari_roms", visualize=False, e=0.1, alpha=0.99,
+                initial_lr=0.0224, lr_annealing_steps=80000000, entropy_regularisation_strength=0.02, clip_norm=3.0,
+                clip_norm_type="global", gamma=0.99, max_global_steps=80000000, max_local_steps=5, arch="NIPS",
+                single_life_episodes=False, emulator_counts=32, emulator_workers=8, debugging_folder="logs/",
+                random_start=True)                # train.py:79-98
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    b = train.get_arg_parser().parse_args("-g breakout -d /gpu:1 -lr 0.01 -lra 100 -ec 64 -ew 4 -df x/ -rs false --arch NATURE".split())
+    assert (b.game, b.device, b.initial_lr, b.lr_annealing_steps, b.emulator_counts, b.emulator_workers,
+            b.debugging_folder, b.random_start, b.arch) == ("breakout", "/gpu:1", 0.01, 100, 64, 4, "x/", False, "NATURE")
+
+
+def test_runners_host_batching():
+    """Runners / EmulatorRunner (own implementation) against the oracle's step loop, in-process and with workers."""
+    from paac_amd.runners import EmulatorRunner, Runners
+    from paac_amd.synthetic import SyntheticEnvironment
+    N, A = 4, 4
+    for workers in (0, 2):
+        envs = [SyntheticEnvironment(i, A, seed=1, terminal_p=0.3) for i in range(N)]
+        twin = [SyntheticEnvironment(i, A, seed=1, terminal_p=0.3) for i in range(N)]
+        variables = [np.asarray([e.get_initial_state() for e in envs], dtype=np.uint8), np.zeros(N, np.float32),
+                     np.zeros(N, np.float32), np.zeros((N, A), np.float32)]
+        for e in twin:
+            e.get_initial_state()
+        r = Runners(EmulatorRunner, envs, workers, variables)
+        r.start()
+        s, rew, over, act = r.get_shared_variables()
+        rs = np.random.RandomState(0)
+        for _ in range(6):
+            idx = rs.randint(0, A, N)
+            act[...] = np.eye(A, dtype=np.float32)[idx]
+            r.update_environments()
+            r.wait_updated()
+            for i, e in enumerate(twin):
+                o, rr, t = e.next(np.eye(A)[idx[i]])
+                if t:
+                    o = e.get_initial_state()
+                assert np.array_equal(s[i], o) and rew[i] == rr and bool(over[i]) == t
+        r.stop()
+        for p in r.runners:
+            p.join(timeout=5)

@@ -1,0 +1,252 @@
+"""-m gpu: returns / lr / samplers / preprocessing / synthetic envs vs the oracle and the golden vectors
+(bit-exact for bytes and action indices), through the C-ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import preprocess as opre
+from oracle import rollout as oroll
+from oracle import sampler as osamp
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "rollout_*.npz")))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("T,N", [(5, 32), (20, 128), (5, 1), (1, 7)])
+def test_nstep_returns_bit_exact(T, N):
+    from paac_amd import hip_ops
+    rs = np.random.RandomState(T * 100 + N)
+    v_boot = rs.randn(N).astype(np.float32)
+    rewards = rs.choice([-1.0, 0.0, 1.0], size=(T, N)).astype(np.float32)
+    masks = (rs.rand(T, N) > 0.2).astype(np.float32)
+    values = rs.randn(T, N).astype(np.float32)
+    y = torch.zeros(T * N, device="cuda")
+    adv = torch.zeros(T * N, device="cuda")
+    hip_ops.nstep_returns(dev(v_boot), dev(rewards), dev(masks), dev(values), 0.99, y, adv)
+    ye, ae = oroll.nstep_returns(v_boot, rewards.astype(np.float64), masks.astype(np.float64),
+                                 values.astype(np.float64), 0.99)
+    assert np.array_equal(y.cpu().numpy(), ye.reshape(-1).astype(np.float32))
+    assert np.array_equal(adv.cpu().numpy(), ae.reshape(-1).astype(np.float32))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_returns_and_sampler(path):
+    """Reference-captured vectors: pi -> actions (MT19937 stream incl. final position), rewards/masks/values -> y, adv."""
+    from paac_amd import hip_ops
+    g = np.load(path)
+    N, T, A = int(g["N"]), int(g["T"]), int(g["A"])
+    rs = np.random.RandomState(int(g["seed"]))
+    state = hip_ops.mt_state_from_numpy(rs.get_state(), "cuda")
+    scratch = hip_ops.sample_mt_scratch(N, A, "cuda")
+    for c in range(int(g["cycles"])):
+        acts = torch.zeros((T, N), dtype=torch.int32, device="cuda")
+        for t in range(T):
+            hip_ops.sample_mt(dev(g["pi"][c, t]), state, scratch, acts[t])
+        want = np.argmax(g["actions"][c], axis=1).reshape(T, N)
+        assert np.array_equal(acts.cpu().numpy(), want), "cycle %d sampled actions differ from the reference" % c
+    st = hip_ops.mt_state_to_numpy(state)
+    import hashlib
+    assert st[2] == int(g["mt_pos"])
+    assert hashlib.sha256(np.asarray(st[1], dtype=np.uint32).tobytes()).hexdigest() == str(g["mt_key_sha256"])
+    # returns: reconstruct rewards/masks from the fixture's y/adv is circular, so recompute them from the oracle replay
+    from test_oracle_golden import replay_oracle
+    ro, cycles, _ = replay_oracle(g)
+    for c, cyc in enumerate(cycles):
+        y = torch.zeros(T * N, device="cuda")
+        adv = torch.zeros(T * N, device="cuda")
+        hip_ops.nstep_returns(dev(cyc["v_boot"].astype(np.float32)), dev(cyc["rewards"].astype(np.float32)),
+                              dev(cyc["masks"].astype(np.float32)), dev(cyc["values"].astype(np.float32)),
+                              float(g["gamma"]), y, adv)
+        assert np.array_equal(y.cpu().numpy(), g["y"][c].astype(np.float32))
+        assert np.array_equal(adv.cpu().numpy(), g["adv"][c].astype(np.float32))
+
+
+@pytest.mark.parametrize("N,A", [(32, 4), (8, 6), (16, 18), (256, 4), (1024, 18), (3, 2), (5, 32)])
+def test_sampler_mt_matches_numpy(N, A):
+    from paac_amd import hip_ops
+    gen = np.random.RandomState(N * 31 + A)
+    rs = np.random.RandomState(1234)
+    rs.random_sample(N % 7)            # start from an arbitrary stream position
+    state = hip_ops.mt_state_from_numpy(rs.get_state(), "cuda")
+    scratch = hip_ops.sample_mt_scratch(N, A, "cuda")
+    acts = torch.zeros(N, dtype=torch.int32, device="cuda")
+    for it in range(12):
+        logits = gen.randn(N, A) * 2.0
+        p = np.exp(logits - logits.max(1, keepdims=True))
+        p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        p = np.maximum(p, 1e-6).astype(np.float32)
+        p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        hip_ops.sample_mt(dev(p), state, scratch, acts)
+        want = osamp.sample_numpy_reference(p, rs)
+        assert np.array_equal(acts.cpu().numpy(), np.asarray(want, dtype=np.int32)), "iteration %d" % it
+        st = hip_ops.mt_state_to_numpy(state)
+        ref = rs.get_state()
+        assert st[2] == ref[2] and np.array_equal(st[1], ref[1]), "MT19937 stream diverged at iteration %d" % it
+
+
+def test_sampler_mt_edge_probabilities():
+    from paac_amd import hip_ops
+    # one-hot-ish rows and an exact-zero category (numpy draws nothing for p == 0)
+    eps = np.float32(np.finfo(np.float32).epsneg)
+    p = np.array([[eps, 1.0 - 1e-6, 1e-6], [0.5, 0.5, 0.0], [1e-6, 1e-6, 1.0 - 2e-6], [1 / 3, 1 / 3, 1 / 3]], dtype=np.float32)
+    p[0, 0] = eps            # p - epsneg == 0 exactly
+    rs_a = np.random.RandomState(5)
+    rs_b = np.random.RandomState(5)
+    state = hip_ops.mt_state_from_numpy(rs_a.get_state(), "cuda")
+    scratch = hip_ops.sample_mt_scratch(4, 3, "cuda")
+    acts = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for _ in range(20):
+        hip_ops.sample_mt(dev(p), state, scratch, acts)
+        want, _ = osamp.sample_mt_restated(p, rs_b)
+        assert np.array_equal(acts.cpu().numpy(), np.asarray(want, dtype=np.int32))
+    assert hip_ops.mt_state_to_numpy(state)[2] == rs_b.get_state()[2]
+
+
+@pytest.mark.parametrize("N,A", [(32, 4), (100, 18)])
+def test_sampler_philox_matches_spec(N, A):
+    from paac_amd import hip_ops
+    gen = np.random.RandomState(7)
+    logits = gen.randn(N, A)
+    p = np.exp(logits)
+    p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+    acts = torch.zeros(N, dtype=torch.int32, device="cuda")
+    base = torch.tensor([123456789012], dtype=torch.int64, device="cuda")
+    for off in (0, 3):
+        hip_ops.sample_philox(dev(p), 42, base, off, 5, acts)
+        want = osamp.sample_philox(p, 42, 123456789012 + off, env_offset=5)
+        assert np.array_equal(acts.cpu().numpy(), want)
+    hip_ops.counter_add(base, 7)
+    assert int(base.item()) == 123456789012 + 7
+
+
+def test_lr_step():
+    from paac_amd import hip_ops
+    gs = torch.tensor([0], dtype=torch.int64, device="cuda")
+    lr = torch.zeros(1, device="cuda")
+    step = 0
+    for inc in (160, 160, 79999680, 5):
+        hip_ops.lr_step(gs, inc, 0.0224, 80000000, lr)
+        step += inc
+        assert int(gs.item()) == step
+        assert lr.item() == np.float32(oroll.get_lr(step, 0.0224, 80000000))
+
+
+@pytest.mark.parametrize("rgb", [False, True])
+def test_preprocess_stack_bit_exact(rgb):
+    from paac_amd import hip_ops
+    rs = np.random.RandomState(11)
+    N = 5
+    shape = (N, 2, 210, 160, 3) if rgb else (N, 2, 210, 160)
+    raw = rs.randint(0, 256, shape).astype(np.uint8)
+    stack = rs.randint(0, 256, (N, 84, 84, 4)).astype(np.uint8)
+    push = np.array([1, 1, 0, 1, 1], dtype=np.uint8)
+    reset = np.array([0, 1, 0, 0, 0], dtype=np.uint8)
+    out = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda")
+    hip_ops.preprocess_stack(dev(raw), dev(stack), out, dev(push), dev(reset))
+    want = np.empty_like(stack)
+    for e in range(N):
+        fr = opre.rgb_to_gray(raw[e]) if rgb else raw[e]
+        plane = opre.max_resize(fr)
+        base = np.zeros_like(stack[e]) if reset[e] else stack[e]
+        want[e] = opre.push_observation(base, plane) if push[e] else stack[e]
+    assert np.array_equal(out.cpu().numpy(), want)
+    # in place, no masks
+    s2 = dev(stack)
+    hip_ops.preprocess_stack(dev(raw), s2, s2)
+    want2 = np.stack([opre.push_observation(stack[e], opre.max_resize(opre.rgb_to_gray(raw[e]) if rgb else raw[e]))
+                      for e in range(N)])
+    assert np.array_equal(s2.cpu().numpy(), want2)
+
+
+@pytest.mark.parametrize("path", GOLDEN[:1], ids=[os.path.basename(p) for p in GOLDEN[:1]])
+def test_preprocess_reproduces_reference_states(path):
+    """Raw frames of the golden env (regenerated from its seeds) pushed through the HIP kernel reproduce the
+    stacked states the reference's FramePool/ObservationPool + PIL produced."""
+    from golden_env import GoldenEnv
+    from paac_amd import hip_ops
+    g = np.load(path)
+    N, T, A = int(g["N"]), int(g["T"]), int(g["A"])
+    envs = [GoldenEnv(i, A, opre.FramePoolOracle, opre.ObservationPoolOracle, opre.max_resize, float(g["terminal_p"]))
+            for i in range(N)]
+    for e in envs:
+        e.raw_log = []
+        e.get_initial_state()
+    stack = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda")
+    for k in range(4):        # initial state = 4 pushes (atari_emulator.py:88-96)
+        hip_ops.preprocess_stack(dev(np.stack([e.raw_log[k] for e in envs])), stack, stack)
+    states0 = g["states"][0].reshape(T, N, 84, 84, 4)
+    assert np.array_equal(stack.cpu().numpy(), states0[0])
+    acts = np.argmax(g["actions"][0], axis=1).reshape(T, N)
+    # one more step without resets: env e continues unless it hit a terminal
+    nxt, over = [], []
+    for i, e in enumerate(envs):
+        e.raw_log = []
+        obs, r, term = e.next(np.eye(A)[acts[0, i]])
+        nxt.append(e.raw_log[0])
+        over.append(term)
+    hip_ops.preprocess_stack(dev(np.stack(nxt)), stack, stack)
+    got = stack.cpu().numpy()
+    for i in range(N):
+        if not over[i]:
+            assert np.array_equal(got[i], states0[1, i])
+
+
+@pytest.mark.parametrize("raw_frames", [False, True])
+def test_synthetic_env_matches_host_spec(raw_frames):
+    from paac_amd import hip_ops
+    from paac_amd.synthetic import SyntheticEnvironment, terminal_threshold
+    N, A, seed, off, p = 6, 4, 3, 10, 0.2
+    envs = [SyntheticEnvironment(off + i, A, seed=seed, terminal_p=p, raw_frames=raw_frames) for i in range(N)]
+    host = np.stack([e.get_initial_state() for e in envs])
+    raw = torch.zeros((N, 2, 210, 160), dtype=torch.uint8, device="cuda") if raw_frames else None
+    a = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda")
+    b = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda")
+    hip_ops.synth_reset(seed, off, a, raw)
+    assert np.array_equal(a.cpu().numpy(), host)
+    tick = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rew = torch.zeros(N, device="cuda")
+    msk = torch.zeros(N, device="cuda")
+    ep_r = torch.zeros(N, device="cuda")
+    ep_l = torch.zeros(N, dtype=torch.int32, device="cuda")
+    fin = torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device="cuda")
+    rs = np.random.RandomState(0)
+    tot_r = np.zeros(N)
+    tot_l = np.zeros(N, dtype=int)
+    finished = []
+    for step in range(25):
+        acts = rs.randint(0, A, N).astype(np.int32)
+        hip_ops.synth_step(seed, off, dev(acts), terminal_threshold(p), tick, step % 3, a, b, rew, msk, ep_r, ep_l, fin,
+                           raw_scratch=raw)
+        if step % 3 == 2:
+            hip_ops.counter_add(tick, 3)
+        want_s, want_r, want_m = [], [], []
+        for i, e in enumerate(envs):
+            obs, r, term = e.next(np.eye(A)[acts[i]])
+            tot_r[i] += r
+            tot_l[i] += 1
+            if term:
+                obs = e.get_initial_state()
+                finished.append((tot_r[i], tot_l[i]))
+                tot_r[i], tot_l[i] = 0, 0
+            want_s.append(obs)
+            want_r.append(oroll.rescale_reward(r))
+            want_m.append(0.0 if term else 1.0)
+        assert np.array_equal(b.cpu().numpy(), np.stack(want_s)), "step %d" % step
+        assert np.array_equal(rew.cpu().numpy(), np.asarray(want_r, dtype=np.float32))
+        assert np.array_equal(msk.cpu().numpy(), np.asarray(want_m, dtype=np.float32))
+        a, b = b, a
+    assert len(finished) > 0
+    f = fin.cpu().numpy()
+    assert int(f[0]) == len(finished)
+    got = sorted(zip(f[2:2 + len(finished)].view(np.float32).tolist(), f[2 + 4096:2 + 4096 + len(finished)].tolist()))
+    assert got == sorted((float(r), int(l)) for r, l in finished)
+    assert np.array_equal(ep_r.cpu().numpy(), tot_r.astype(np.float32))
+    assert np.array_equal(ep_l.cpu().numpy(), tot_l.astype(np.int32))

@@ -1,0 +1,147 @@
+"""-m gpu: HIP forward / backward / optimizer vs the float64 oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import network as onet
+
+ARCH_ID = {"NIPS": 0, "NATURE": 1}
+
+
+def make_case(arch, A, B, seed=0, weight_scale=1.0):
+    rs = np.random.RandomState(seed)
+    params = onet.init_params(arch, A, rs, dtype=np.float32)
+    if weight_scale != 1.0:
+        for k in params:
+            params[k] = (params[k] * weight_scale).astype(np.float32)
+    states = rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)
+    idx = rs.randint(0, A, B).astype(np.int32)
+    y = rs.randn(B).astype(np.float32)
+    adv = rs.randn(B).astype(np.float32)
+    return params, states, idx, y, adv
+
+
+def upload_params(ctx, params):
+    from paac_amd import _lib
+    lay = ctx.layout
+    host = np.zeros(lay["total"], dtype=np.float32)
+    for t in lay["tensors"]:
+        host[t["offset"]:t["offset"] + t["size"]] = params[t["name"]].reshape(-1)
+    return torch.from_numpy(host).cuda()
+
+
+def unflatten(ctx, flat):
+    host = flat.detach().cpu().numpy()
+    return {t["name"]: host[t["offset"]:t["offset"] + t["size"]].reshape(t["shape"]) for t in ctx.layout["tensors"]}
+
+
+@pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 32), ("NATURE", 4, 160), ("NATURE", 18, 7), ("NATURE", 6, 1),
+                                      ("NIPS", 6, 40), ("NIPS", 4, 33), ("NIPS", 18, 160)])
+def test_forward_parity(arch, A, B):
+    from paac_amd import hip_ops
+    params, states, idx, y, adv = make_case(arch, A, B, seed=1)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=max(B, 8))
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    logits = torch.zeros((B, A), device="cuda")
+    probs = torch.zeros((B, A), device="cuda")
+    values = torch.zeros((B,), device="cuda")
+    ctx.forward(p, s, logits, probs, values)
+    torch.cuda.synchronize()
+    ref = onet.forward(params, states, arch, dtype=np.float64, keep=True)
+    nconv = 3 if arch == "NATURE" else 2
+    for i in range(nconv):
+        got = ctx.debug_activation(i + 1, B).cpu().numpy()
+        want = ref["cache"]["a%d" % (i + 1)].reshape(-1)
+        assert got.shape == want.shape
+        err = np.abs(got - want).max()
+        assert err < 2e-5, "conv%d activations: max abs err %g" % (i + 1, err)
+    h = ctx.debug_activation(4, B).cpu().numpy()
+    assert np.abs(h - ref["cache"]["h"].reshape(-1)).max() < 5e-5
+    # north_star tolerance: logits / values within 1e-4 of the reference-equivalent CPU path
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
+    assert np.abs(probs.cpu().numpy() - ref["pi"]).max() < 1e-5
+    ctx.close()
+
+
+@pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NATURE", 6, 40), ("NATURE", 18, 9), ("NIPS", 6, 40),
+                                      ("NIPS", 4, 160), ("NATURE", 4, 320)])
+def test_backward_parity(arch, A, B):
+    from paac_amd import hip_ops
+    params, states, idx, y, adv = make_case(arch, A, B, seed=2)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    grad = torch.zeros(ctx.layout["total"], device="cuda")
+    loss = torch.zeros(4, device="cuda")
+    ctx.loss_backward(p, s, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(adv).cuda(),
+                      0.02, grad, loss)
+    torch.cuda.synchronize()
+    L, g_ref = onet.loss_and_grads(params, states, np.eye(A)[idx], y, adv, 0.02, arch, dtype=np.float64)
+    lo = loss.cpu().numpy()
+    assert abs(lo[0] - L["loss"]) < 1e-4 * max(1.0, abs(L["loss"]))
+    assert abs(lo[1] - L["actor"]) < 1e-4 and abs(lo[2] - L["critic"]) < 1e-4
+    assert abs(lo[3] - L["entropy"].mean()) < 1e-4
+    got = unflatten(ctx, grad)
+    gn_ref = onet.global_norm(g_ref)
+    for name, want in g_ref.items():
+        err = np.abs(got[name] - want).max()
+        scale = max(np.abs(want).max(), 1e-3 * gn_ref)
+        assert err / scale < 1e-4, "%s: max abs err %g (scale %g)" % (name, err, scale)
+    # pads stay zero
+    flat = grad.cpu().numpy()
+    used = np.zeros(flat.shape, dtype=bool)
+    for t in ctx.layout["tensors"]:
+        used[t["offset"]:t["offset"] + t["size"]] = True
+    assert np.all(flat[~used] == 0.0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,gscale", [("global", 1.0), ("ignore", 1.0), ("global", 0.5)])
+def test_clip_rmsprop_parity(mode, gscale):
+    from paac_amd import hip_ops, _lib
+    arch, A = "NATURE", 6
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=8)
+    n = ctx.layout["total"]
+    rs = np.random.RandomState(3)
+    var = rs.randn(n).astype(np.float32) * 0.1
+    g = rs.randn(n).astype(np.float32) * (0.01 if mode == "global" else 0.001)
+    ms = (1.0 + rs.rand(n)).astype(np.float32)
+    mom = np.zeros(n, dtype=np.float32)
+    lr = np.float32(0.0224)
+    dv, dg, dms, dmom = [torch.from_numpy(a.copy()).cuda() for a in (var, g, ms, mom)]
+    lr_dev = torch.tensor([lr], device="cuda")
+    gn_dev = torch.zeros(1, device="cuda")
+    ctx.clip_rmsprop(dv, dg, dms, dmom, lr_dev, 0.99, 0.0, 0.1, 3.0,
+                     _lib.CLIP_GLOBAL if mode == "global" else _lib.CLIP_IGNORE, gscale, gn_dev)
+    torch.cuda.synchronize()
+    gs = g.astype(np.float64) * gscale
+    gn = np.sqrt((gs ** 2).sum())
+    f = 3.0 * min(1.0 / gn, 1.0 / 3.0) if mode == "global" else 1.0
+    gc = gs * f
+    ms_e = ms + (gc * gc - ms) * 0.01
+    mom_e = lr * gc / np.sqrt(ms_e + 0.1)
+    var_e = var - mom_e
+    assert abs(gn_dev.item() - gn) / gn < 1e-5
+    assert np.abs(dms.cpu().numpy() - ms_e).max() < 1e-6
+    assert np.abs(dmom.cpu().numpy() - mom_e).max() < 1e-7
+    assert np.abs(dv.cpu().numpy() - var_e).max() < 1e-6
+    ctx.close()
+
+
+def test_errors_are_loud():
+    from paac_amd import hip_ops, _lib
+    ctx = hip_ops.Context(1, 4, max_batch=8)
+    p = torch.zeros(ctx.layout["total"], device="cuda")
+    with pytest.raises(ValueError):
+        ctx.forward(p, torch.zeros((9, 84, 84, 4), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        ctx.forward(p, torch.zeros((4, 84, 84, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        ctx.forward(p[:100], torch.zeros((4, 84, 84, 4), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(_lib.PaacHipError):
+        hip_ops.Context(1, 99, max_batch=8)
+    ctx.close()

@@ -1,0 +1,167 @@
+"""-m gpu: the whole PAAC cycle through the drop-in surface vs the oracle restatement of paac.py:59-183."""
+import argparse
+import copy
+import tempfile
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import network as onet
+from oracle import rollout as oroll
+from oracle import sampler as osamp
+
+
+def make_args(**kw):
+    from paac_amd import train
+    args = train.get_arg_parser().parse_args([])
+    args.debugging_folder = tempfile.mkdtemp(prefix="paac_test_")
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return args
+
+
+def build_learner(args, params_seed=0):
+    from paac_amd import train
+    from paac_amd.paac import PAACLearner
+    network_creator, env_creator = train.get_network_and_environment_creator(args)
+    learner = PAACLearner(network_creator, env_creator, args)
+    arch = "NIPS" if args.arch == "NIPS" else "NATURE"
+    params = onet.init_params(arch, args.num_actions, np.random.RandomState(params_seed), dtype=np.float32)
+    learner.network.set_parameters(params)
+    learner.network.init = lambda folder, saver, session: 0      # keep the injected weights
+    return learner, params, env_creator
+
+
+def oracle_cycles(args, params, env_creator, cycles, arch):
+    """The reference loop restated on the CPU: same envs, same np.random sampler stream, fp32-param / fp64-math net."""
+    A, N, T = args.num_actions, args.emulator_counts, args.max_local_steps
+    envs = [env_creator.create_environment(i) for i in range(N)]
+    rs = np.random.RandomState(args.test_seed)
+    p = {k: v.copy() for k, v in params.items()}
+    ms, mom = onet.rmsprop_init(p)
+
+    def policy_fn(states):
+        out = onet.forward(p, states, arch, dtype=np.float64)
+        return out["v"].astype(np.float32), out["pi"].astype(np.float32)
+
+    ro = oroll.OracleRollout(envs, A, T, args.gamma, args.initial_lr, args.lr_annealing_steps, policy_fn,
+                             lambda pi: osamp.sample_mt_restated(pi, rs)[0])
+    outs = []
+    for _ in range(cycles):
+        cyc = ro.cycle()
+        L, g = onet.loss_and_grads(p, cyc["states"], cyc["actions"], cyc["y"].astype(np.float32),
+                                   cyc["adv"].astype(np.float32), args.entropy_regularisation_strength, arch,
+                                   dtype=np.float64)
+        gc, gn = onet.clip_by_global_norm(g, args.clip_norm, args.clip_norm_type)
+        p, ms, mom = onet.rmsprop_step(p, {k: v.astype(np.float32) for k, v in gc.items()}, ms, mom,
+                                       np.float32(cyc["lr"]), args.alpha, 0.0, args.e)
+        cyc["params"] = {k: v.copy() for k, v in p.items()}
+        cyc["gnorm"] = gn
+        outs.append(cyc)
+    return outs
+
+
+@pytest.mark.parametrize("game,arch,N,T", [("pong", "NIPS", 8, 5), ("breakout", "NATURE", 8, 5)])
+def test_host_loop_matches_oracle(game, arch, N, T):
+    """BASELINE config 1 (Pong / NIPS / 8 envs / t_max 5) and a Nature twin, host BaseEnvironment plugins."""
+    cycles = 3
+    feeds = []
+    args = make_args(game=game, arch=arch, emulator_counts=N, emulator_workers=0, max_local_steps=T,
+                     max_global_steps=cycles * N * T, host_environments=True, record_feeds=True,
+                     feed_callback=feeds.append, synthetic_terminal_p=0.1, test_seed=42)
+    learner, params, env_creator = build_learner(args)
+    np.random.seed(args.test_seed)
+    learner.train()
+    want = oracle_cycles(args, params, env_creator, cycles, "NIPS" if arch == "NIPS" else "NATURE")
+    assert len(feeds) == cycles
+    for c in range(cycles):
+        assert np.array_equal(feeds[c]["states"], want[c]["states"]), "states differ in cycle %d" % c
+        assert np.array_equal(feeds[c]["actions"], np.argmax(want[c]["actions"], axis=1)), "actions differ in cycle %d" % c
+        assert np.abs(feeds[c]["values"] - want[c]["values"]).max() < 1e-4
+        assert np.abs(feeds[c]["y"] - want[c]["y"]).max() < 2e-4
+        assert feeds[c]["lr"] == want[c]["lr"]
+        assert feeds[c]["global_step"] == want[c]["global_step"]
+    got = learner.network.get_parameters()
+    for k, v in want[-1]["params"].items():
+        assert np.abs(got[k] - v).max() < 2e-4, k
+    # sampler stream position was written back to the global np.random like the reference leaves it
+    rs = np.random.RandomState(args.test_seed)
+    for c in range(cycles):
+        for t in range(T):
+            osamp.sample_mt_restated(want[c]["pis"][t], rs)
+    assert np.random.get_state()[2] == rs.get_state()[2]
+
+
+@pytest.mark.parametrize("raw_frames,use_graph", [(False, False), (False, True), (True, True)])
+def test_device_loop_matches_host_loop(raw_frames, use_graph):
+    """Device-resident cycle (hipGraph replay, device envs) == the host loop on the same envs and sampler stream."""
+    N, T, cycles = 8, 5, 4
+    common = dict(game="breakout", arch="NATURE", emulator_counts=N, emulator_workers=0, max_local_steps=T,
+                  max_global_steps=cycles * N * T, synthetic_terminal_p=0.1, synthetic_raw_frames=raw_frames)
+    feeds = []
+    a_host = make_args(host_environments=True, record_feeds=True, feed_callback=feeds.append, **common)
+    host, params, _ = build_learner(a_host)
+    np.random.seed(7)
+    host.train()
+    a_dev = make_args(sampler="numpy", use_graph=use_graph, **common)
+    devl, _, _ = build_learner(a_dev)
+    np.random.seed(7)
+    devl.global_step = devl.init_network()
+    from paac_amd.paac import DeviceRollout
+    ro = DeviceRollout(devl, devl.environment_creator.device_env_spec, sampler="numpy", use_graph=use_graph)
+    for c in range(cycles):
+        ro.run_cycle()
+        ro.synchronize()
+        assert np.array_equal(ro.states[:T].reshape(T * N, 84, 84, 4).cpu().numpy(), feeds[c]["states"]), "cycle %d" % c
+        assert np.array_equal(ro.actions.view(-1).cpu().numpy(), feeds[c]["actions"])
+        assert np.allclose(ro.y.cpu().numpy(), feeds[c]["y"], atol=1e-5)
+        assert abs(devl.lr_dev.item() - np.float32(feeds[c]["lr"])) == 0.0
+    gh = host.network.get_parameters()
+    gd = devl.network.get_parameters()
+    for k in gh:
+        assert np.abs(gh[k] - gd[k]).max() < 1e-5, k
+    assert int(ro.global_step_dev.item()) == cycles * N * T
+    ro.close()
+
+
+def test_choose_next_actions_dropin():
+    """Static helper used by the reference's test.py:77 -- same signature, numpy in/out, global np.random stream."""
+    from paac_amd.paac import PAACLearner
+    args = make_args(game="qbert", arch="NATURE", emulator_counts=4, max_local_steps=2, max_global_steps=0)
+    learner, params, _ = build_learner(args)
+    states = np.random.RandomState(0).randint(0, 256, (4, 84, 84, 4)).astype(np.uint8)
+    np.random.seed(3)
+    acts, v, pi = PAACLearner.choose_next_actions(learner.network, args.num_actions, states, learner.session)
+    ref = onet.forward(params, states, "NATURE", dtype=np.float64)
+    assert acts.shape == (4, args.num_actions) and np.all(acts.sum(1) == 1)
+    assert np.abs(pi - ref["pi"]).max() < 1e-5 and np.abs(v - ref["v"]).max() < 1e-4
+    rs = np.random.RandomState(3)
+    want, _ = osamp.sample_mt_restated(pi, rs)
+    assert list(np.argmax(acts, 1)) == want
+    assert np.random.get_state()[2] == rs.get_state()[2]
+
+
+def test_checkpoint_roundtrip():
+    args = make_args(game="pong", arch="NIPS", emulator_counts=4, max_local_steps=2, max_global_steps=16)
+    learner, params, _ = build_learner(args)
+    learner.train()                       # 2 cycles on device envs, cleanup() saves
+    saved = learner.network.get_parameters()
+    a2 = copy.copy(args)
+    from paac_amd import train
+    from paac_amd.paac import PAACLearner
+    nc, ec = train.get_network_and_environment_creator(a2)
+    l2 = PAACLearner(nc, ec, a2)
+    step = l2.init_network()
+    assert step == 16
+    for k, v in l2.network.get_parameters().items():
+        assert np.array_equal(v, saved[k])
+    assert torch.equal(l2.rms, learner.rms)
+
+
+def test_cpu_device_is_rejected():
+    args = make_args(device="/cpu:0", emulator_counts=2)
+    with pytest.raises(RuntimeError):
+        build_learner(args)
