@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- global env-steps/s of the PAAC hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one full PAAC cycle (paac.py:99-183): T x [policy forward -> sample -> env step] -> bootstrap
+forward -> n-step returns -> forward/backward on the N*T batch -> (RCCL gradient all-reduce) -> clip +
+RMSProp, on synthetic 84x84x4 uint8 frames generated on the device; value = env-steps of all ranks / the
+slowest rank's wall time (weak scaling: 32 envs per GPU).  Workload at N=1 = BASELINE configs[1]
+(Breakout action set, Nature net, 32 envs, t_max=5).
+
+Extra objects on the JSON line:
+  roofline     -- the kernel family with the largest share of the cycle, timed with HIP events on the launch
+                  stream in a second, eager (graph-free) pass over the same K steps; achieved = algorithmic
+                  FLOPs (or bytes) per launch / average launch duration.
+  cpu_baseline -- oracle/cpu_learner.py (torch-CPU port of the reference loop; the reference's TF path cannot
+                  run here) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def family_work(name, batch, arch, A, P):
+    """Algorithmic work of one launch of a kernel family: (kind, amount) with kind 'flop' or 'byte'."""
+    if arch == "NATURE":
+        C1, C2, C3, H, FLAT = 32, 64, 64, 512, 3136
+        conv3 = 2.0 * batch * 49 * 576 * 64
+    else:
+        C1, C2, C3, H, FLAT = 16, 32, 32, 256, 2592
+        conv3 = 0.0
+    conv1 = 2.0 * batch * 400 * 256 * C1
+    conv2 = 2.0 * batch * 81 * (16 * C1) * C2
+    fc = 2.0 * batch * FLAT * H
+    table = {"conv1_fwd": conv1, "conv1_wgrad": conv1, "conv2_fwd": conv2, "conv2_wgrad": conv2, "conv2_dgrad": conv2,
+             "conv3_fwd": conv3, "conv3_wgrad": conv3, "conv3_dgrad": conv3, "fc_fwd": fc, "fc_wgrad": fc, "fc_dgrad": fc}
+    if name in table:
+        return "flop", table[name]
+    if name == "clip_rmsprop":      # read g (norm) + read g, ms, mom, var + write ms, mom, var
+        return "byte", 4.0 * P * 8
+    if name == "heads_fwd":
+        return "byte", 4.0 * batch * H * 2 + 4.0 * H * (A + 1)
+    if name == "heads_bwd":
+        return "byte", 4.0 * batch * H * 3 + 4.0 * H * (A + 1) * 2
+    return "byte", 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=32, help="environments per GPU")
+    ap.add_argument("--tmax", type=int, default=5)
+    ap.add_argument("--arch", default="NATURE")
+    ap.add_argument("--game", default="breakout")
+    ap.add_argument("--sampler", default="numpy", choices=["numpy", "philox"])
+    ap.add_argument("--raw-frames", action="store_true", help="path B: raw 210x160 frame pairs + GPU preprocess")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from paac_amd import train
+    from paac_amd.paac import DeviceRollout, PAACLearner
+
+    args = train.get_arg_parser().parse_args([])
+    args.game, args.arch = a.game, a.arch
+    args.emulator_counts, args.max_local_steps = a.envs, a.tmax
+    args.emulator_workers = 0
+    args.device = "/gpu:%d" % local_rank
+    args.max_global_steps = 1 << 60
+    args.synthetic_raw_frames = bool(a.raw_frames)
+    args.debugging_folder = tempfile.mkdtemp(prefix="paac_bench_")
+    network_creator, env_creator = train.get_network_and_environment_creator(args)
+    learner = PAACLearner(network_creator, env_creator, args)
+    learner.network.initialize(np.random.RandomState(0))          # random-init weights (no checkpoints offline)
+    np.random.seed(42 + rank)
+    N, T, A = a.envs, a.tmax, args.num_actions
+    ro = DeviceRollout(learner, env_creator.device_env_spec, sampler=a.sampler, sampler_seed=42, env_offset=rank * N,
+                       use_graph=not a.no_graph)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ro.run_cycle()
+    ro.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ro.run_cycle()
+    ro.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = world * N * T * a.steps / elapsed
+    finite = bool(torch.isfinite(learner.network.params).all().item())
+
+    roofline = None
+    kernels = None
+    if rank == 0 and not a.no_roofline:
+        learner.ctx.prof_enable(True)
+        ro.use_graph = False
+        per = {}
+        steps_done = 0
+        while steps_done < a.steps:
+            chunk = min(a.steps - steps_done, 64)      # 8192-launch event table
+            for _ in range(chunk):
+                ro.run_cycle()
+            ro.synchronize()
+            for name, batch, ms in learner.ctx.prof_read():
+                d = per.setdefault((name, batch), [0.0, 0])
+                d[0] += ms
+                d[1] += 1
+            steps_done += chunk
+        learner.ctx.prof_enable(False)
+        ro.use_graph = not a.no_graph
+        P = learner.network.layout["total_unpadded"]
+        arch = "NIPS" if a.arch == "NIPS" else "NATURE"
+        kernels = []
+        for (name, batch), (ms, cnt) in per.items():
+            kind, amount = family_work(name, batch, arch, A, P)
+            avg_us = 1000.0 * ms / cnt
+            ach = amount / (avg_us * 1e-6) if avg_us > 0 else 0.0
+            kernels.append(dict(kernel=name, batch=batch, launches_per_step=cnt / a.steps, avg_us=round(avg_us, 3),
+                                us_per_step=round(1000.0 * ms / a.steps, 2),
+                                achieved=round(ach / 1e12, 3) if kind == "flop" else round(ach / 1e9, 1),
+                                unit="TFLOP/s" if kind == "flop" else "GB/s"))
+        kernels.sort(key=lambda k: -k["us_per_step"])
+        dom = kernels[0]
+        if dom["unit"] == "TFLOP/s":
+            roofline = dict(bound="mfma", kernel="%s[batch=%d]" % (dom["kernel"], dom["batch"]), achieved=dom["achieved"],
+                            peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                            avg_launch_us=dom["avg_us"], traffic=None)
+        else:
+            roofline = dict(bound="hbm", kernel="%s[batch=%d]" % (dom["kernel"], dom["batch"]), achieved=dom["achieved"],
+                            peak=PEAK_HBM_GBS, unit="GB/s", frac=round(dom["achieved"] / PEAK_HBM_GBS, 4),
+                            avg_launch_us=dom["avg_us"], traffic=None)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import cpu_learner, network as onet          # the oracle is the baseline leg, never the product
+        envs = [env_creator.create_environment(i) for i in range(N)]
+        params = onet.init_params(a.arch, A, np.random.RandomState(0), dtype=np.float32)
+        res = cpu_learner.run(envs, a.arch, A, T, params, min_seconds=a.cpu_seconds)
+        cpu_baseline = dict(value=round(res["steps_per_s"], 1), unit="env-steps/s", cores=res["cores"], kind="port",
+                            sample="%d cycles of the same workload (%d envs x t_max %d, %s net) in %.1f s, torch-CPU fp32 port "
+                                   "of the reference loop" % (res["cycles"], N, T, a.arch, res["seconds"]))
+
+    if rank == 0:
+        out = {
+            "metric": "global env-steps/sec at 32 envs, t_max=5, Nature net; 1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1000.0 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s action set (A=%d), %s net, %d envs per GPU x %d GPU, t_max=%d, %s, sampler=%s, %s"
+                                   % (a.game, A, a.arch, N, world, T,
+                                      "raw 210x160 frame pairs + GPU max/resize/stack" if a.raw_frames else
+                                      "synthetic 84x84x4 u8 frames generated on device",
+                                      a.sampler, "hipGraph replay" if not a.no_graph else "eager launches"),
+                       "envs_per_gpu": N, "t_max": T, "global_envs": N * world,
+                       "parallelism": "env-sharded dp%d, one RCCL all-reduce of the flat gradient per update" % world},
+            "finite_params": finite,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    ro.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,13 @@ int paac_destroy(paac_ctx* ctx);
 int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch,
                  float* logits, float* probs, float* values, paac_stream_t stream);
 
+/* paac_forward fused with the counter-based categorical sampler (paac_sample_philox semantics) in the heads
+ * kernel: what one PAACLearner.choose_next_actions call (paac.py:18-29) costs on the device-resident loop.
+ * probs/values nullable; actions int32[batch]. */
+int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                        float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
+                        uint32_t env_offset, int32_t* actions, paac_stream_t stream);
+
 /* Loss + gradients of policy_v_network.py:29-57 through the whole network (what
  * optimizer.compute_gradients(loss), actor_learner.py:44, evaluates): runs the training forward
  * on `states`, then backward.  actions = sampled action index per row (the one-hot's argmax,
@@ -155,12 +162,17 @@ int paac_graph_destroy(paac_graph* g);
  * what: 1..3 = conv outputs a1..a3 [batch,OH,OW,C], 4 = fc activations h [batch,H]. Returns element count. */
 int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream);
 
-/* Per-kernel timing hooks for bench.py's roofline object: when enabled, every kernel family launch is
- * bracketed by hipEvents on the launch stream.  paac_prof_read synchronises the events and returns
- * accumulated milliseconds + launch counts per family. */
+/* Diagnostic: writes {s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks} to out2_dev[0..1]. */
+int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);
+
+/* Per-kernel timing hooks for bench.py's roofline object: when enabled, every network / optimizer kernel
+ * launch is bracketed by hipEvents on the launch stream (do not enable inside graph capture).
+ * paac_prof_read synchronises the recorded events and returns, per launch, its kernel family, the batch it
+ * processed and its duration in ms (up to max_events; the internal table holds 8192 launches); returns the
+ * number of records written and clears the table. */
 #define PAAC_PROF_FAMILIES 16
 int paac_prof_enable(paac_ctx* ctx, int on);
-int paac_prof_read(paac_ctx* ctx, double* ms_out, int64_t* count_out, int reset);
+int paac_prof_read(paac_ctx* ctx, int32_t* family_out, int32_t* batch_out, float* ms_out, int max_events);
 const char* paac_prof_name(int family);
 
 #ifdef __cplusplus

@@ -164,8 +164,11 @@ def head_grads(pi, v, onehot, y, adv, beta, dtype=np.float64):
     return dlogits, dv
 
 
-def loss_and_grads(params, states_u8, onehot, y, adv, beta, arch, dtype=np.float64):
-    """Full forward + loss + backward.  Returns (loss dict, grads dict in param order)."""
+def loss_and_grads(params, states_u8, onehot, y, adv, beta, arch, dtype=np.float64, relu_masks=None):
+    """Full forward + loss + backward.  Returns (loss dict, grads dict in param order).
+    relu_masks (optional): {"a1".."a3", "h"} boolean arrays overriding relu'(.) in the backward pass -- lets a
+    test take the masks from the implementation under test so that pre-activations within rounding of 0
+    (whose sign legitimately differs between summation orders) do not mask real backward errors."""
     convs, flat, fc = layer_dims(arch)
     fw = forward(params, states_u8, arch, dtype=dtype, keep=True)
     cache = fw["cache"]
@@ -181,7 +184,7 @@ def loss_and_grads(params, states_u8, onehot, y, adv, beta, arch, dtype=np.float
     grads["critic_output_weights"] = h.T @ dv[:, None]
     grads["critic_output_biases"] = dv.sum(keepdims=True)
     dh = dlogits @ params["actor_output_weights"].astype(dtype).T + dv[:, None] @ params["critic_output_weights"].astype(dtype).T
-    dh = dh * (h > 0)
+    dh = dh * ((h > 0) if relu_masks is None else relu_masks["h"].reshape(h.shape))
     n = len(convs) + 1
     grads["fc%d_weights" % n] = cache["xf"].T @ dh
     grads["fc%d_biases" % n] = dh.sum(axis=0)
@@ -190,7 +193,8 @@ def loss_and_grads(params, states_u8, onehot, y, adv, beta, arch, dtype=np.float
         Lc = convs[i]
         a = cache["a%d" % (i + 1)]
         B = a.shape[0]
-        dz = (dx.reshape(a.shape) * (a > 0)).reshape(-1, Lc["cout"])
+        m = (a > 0) if relu_masks is None else relu_masks["a%d" % (i + 1)].reshape(a.shape)
+        dz = (dx.reshape(a.shape) * m).reshape(-1, Lc["cout"])
         cols = cache["cols%d" % (i + 1)]
         grads["conv%d_weights" % (i + 1)] = (cols.T @ dz).reshape(Lc["kh"], Lc["kw"], Lc["cin"], Lc["cout"])
         grads["conv%d_biases" % (i + 1)] = dz.sum(axis=0)

@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpaac_hip.so")
+LIB_PATH = os.environ.get("PAAC_HIP_LIB") or os.path.join(HERE, "libpaac_hip.so")   # PAAC_HIP_LIB: diagnostic builds
 
 MAX_TENSORS = 12
 PROF_FAMILIES = 16
@@ -42,6 +42,8 @@ _SIGNATURES = {
     "paac_create": (c_int, [POINTER(Cfg), POINTER(c_void_p)]),
     "paac_destroy": (c_int, [c_void_p]),
     "paac_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "paac_forward_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_void_p, c_uint64,
+                                    c_uint32, c_void_p, c_void_p]),
     "paac_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p]),
     "paac_clip_rmsprop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float,
@@ -63,8 +65,9 @@ _SIGNATURES = {
     "paac_graph_launch": (c_int, [c_void_p, c_void_p]),
     "paac_graph_destroy": (c_int, [c_void_p]),
     "paac_debug_activation": (c_int64, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "paac_debug_clock": (c_int, [c_void_p, c_void_p]),
     "paac_prof_enable": (c_int, [c_void_p, c_int]),
-    "paac_prof_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), c_int]),
+    "paac_prof_read": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_int]),
     "paac_prof_name": (c_char_p, [c_int]),
 }
 
@@ -81,6 +84,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PaacHipError("%s not found: build it with `python -m paac_amd.build` (hipcc, gfx950). "
                            "paac_amd has no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; the library must bind to THAT runtime instance (device pointers and
+    # streams are torch's), so torch is imported first and the loader reuses the already-loaded SONAME.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, hip_ops
+from . import _lib, hip_ops, parallel
 from .networks import Placeholder
 from .session import Saver, Session
 
@@ -117,19 +117,16 @@ class ActorLearner(object):
         self.ctx.clip_rmsprop(net.params, self.grad, self.rms, self.mom, self.lr_dev, self.alpha, self.momentum,
                               self.e, self.clip_norm, self.clip_mode, self._grad_scale(), self.gnorm_dev)
 
-    # -- data parallel: one sum all-reduce of the flat gradient per update ----------------
+    # -- data parallel: one sum all-reduce of the flat gradient per update (paac_amd/parallel.py) ------
     @staticmethod
     def _world():
-        import torch.distributed as dist
-        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return parallel.world_size()
 
     def _grad_scale(self):
-        return 1.0 / self._world()
+        return parallel.grad_scale()
 
     def _allreduce_grad(self):
-        if self._world() > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        parallel.allreduce_sum_(self.grad)
 
     # -- reference methods ---------------------------------------------------------------------------
     def save_vars(self, force=False):

@@ -41,7 +41,7 @@ int fc_splits_max();
 
 static const char* kFamilyNames[PAAC_PROF_FAMILIES] = {
     "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "heads_fwd", "heads_bwd", "fc_wgrad", "fc_dgrad",
-    "conv_wgrad", "conv_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "sample", "env", "misc"};
+    "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "misc"};
 
 }  // namespace paac
 
@@ -144,6 +144,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   c->ev_start = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
   c->ev_stop = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
   c->ev_family = new int[paac_ctx::PROF_MAX_EVENTS];
+  c->ev_batch = new int[paac_ctx::PROF_MAX_EVENTS];
   c->ev_count = 0;
   c->prof_on = 0;
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
@@ -170,6 +171,7 @@ int paac_destroy(paac_ctx* c) {
   delete[] c->ev_start;
   delete[] c->ev_stop;
   delete[] c->ev_family;
+  delete[] c->ev_batch;
   delete c;
   return 0;
 }
@@ -180,6 +182,19 @@ int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int 
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_forward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
   const int rc = launch_forward(ctx, params, states, batch, true, logits, probs, values, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                        float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
+                        uint32_t env_offset, int32_t* actions, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states && actions, "paac_forward_sample: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_forward_sample: batch %d outside (0, max_batch=%d]", batch,
+               ctx->max_batch);
+  const int rc = launch_forward_sample(ctx, params, states, batch, probs, values, seed, step_base_dev, step_offset,
+                                       env_offset, actions, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -274,25 +289,22 @@ int paac_prof_enable(paac_ctx* ctx, int on) {
   return 0;
 }
 
-int paac_prof_read(paac_ctx* ctx, double* ms_out, int64_t* count_out, int reset) {
+int paac_prof_read(paac_ctx* ctx, int32_t* family_out, int32_t* batch_out, float* ms_out, int max_events) {
   PAAC_REQUIRE(ctx, "paac_prof_read: null ctx");
+  int n = 0;
   for (int i = 0; i < ctx->ev_count; ++i) {
     PAAC_CHECK_HIP(hipEventSynchronize(ctx->ev_stop[i]));
     float ms = 0.f;
     PAAC_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
-    ctx->prof_ms[ctx->ev_family[i]] += ms;
-    ctx->prof_n[ctx->ev_family[i]] += 1;
-  }
-  ctx->ev_count = 0;
-  for (int f = 0; f < PAAC_PROF_FAMILIES; ++f) {
-    if (ms_out) ms_out[f] = ctx->prof_ms[f];
-    if (count_out) count_out[f] = ctx->prof_n[f];
-    if (reset) {
-      ctx->prof_ms[f] = 0.0;
-      ctx->prof_n[f] = 0;
+    if (n < max_events) {
+      if (family_out) family_out[n] = ctx->ev_family[i];
+      if (batch_out) batch_out[n] = ctx->ev_batch[i];
+      if (ms_out) ms_out[n] = ms;
+      ++n;
     }
   }
-  return 0;
+  ctx->ev_count = 0;
+  return n;
 }
 
 const char* paac_prof_name(int family) {

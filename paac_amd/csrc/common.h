@@ -46,8 +46,8 @@ ArchSpec arch_spec(int arch);
 // Kernel families for the timing hooks (paac_prof_*).
 enum Family {
   F_CONV1_FWD = 0, F_CONV2_FWD, F_CONV3_FWD, F_FC_FWD, F_HEADS_FWD,
-  F_HEADS_BWD, F_FC_WGRAD, F_FC_DGRAD, F_CONV_WGRAD, F_CONV_DGRAD, F_CONV1_WGRAD,
-  F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_SAMPLE, F_ENV, F_MISC
+  F_HEADS_BWD, F_FC_WGRAD, F_FC_DGRAD, F_CONV3_WGRAD, F_CONV3_DGRAD, F_CONV2_WGRAD, F_CONV2_DGRAD, F_CONV1_WGRAD,
+  F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_MISC
 };
 static_assert(F_MISC + 1 == PAAC_PROF_FAMILIES, "family count");
 
@@ -79,9 +79,8 @@ struct paac_ctx {
   hipEvent_t* ev_start;
   hipEvent_t* ev_stop;
   int* ev_family;
+  int* ev_batch;
   int ev_count;
-  double prof_ms[PAAC_PROF_FAMILIES];
-  int64_t prof_n[PAAC_PROF_FAMILIES];
 };
 
 namespace paac {
@@ -91,10 +90,11 @@ struct ProfScope {
   paac_ctx* ctx;
   hipStream_t s;
   int idx;
-  ProfScope(paac_ctx* c, int family, hipStream_t stream) : ctx(c), s(stream), idx(-1) {
+  ProfScope(paac_ctx* c, int family, int batch, hipStream_t stream) : ctx(c), s(stream), idx(-1) {
     if (c && c->prof_on && c->ev_count < paac_ctx::PROF_MAX_EVENTS) {
       idx = c->ev_count++;
       c->ev_family[idx] = family;
+      c->ev_batch[idx] = batch;
       (void)hipEventRecord(c->ev_start[idx], s);
     }
   }
@@ -106,6 +106,9 @@ struct ProfScope {
 // launchers implemented in the kernel translation units
 int launch_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, bool want_outputs,
                    float* logits, float* probs, float* values, hipStream_t s);
+int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                          float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
+                          uint32_t env_offset, int32_t* actions, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, hipStream_t s);
 

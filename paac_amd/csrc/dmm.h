@@ -1,0 +1,391 @@
+// Direct-to-register fp32 MFMA contraction for CDNA4 (v_mfma_f32_16x16x4_f32), one template for every
+// GEMM-shaped op of the actor-critic network (conv/fc forward, dgrad, wgrad).
+//
+//   C[M,N] = A[M,K] * B[K,N]
+//
+// Design (MI355X-first, sized for the tiny batches of PAAC: 32 rows when acting, N*T = 160 when training):
+//   * No LDS in the main loop.  Every 64-lane wave owns TM x TN accumulator tiles of 16x16 and loads its own
+//     operand fragments from global memory (L2 / Infinity-Cache resident) straight into the MFMA register
+//     layout -- lane (i = l&15, kq = l>>4) supplies row/column i at k-slot kq.  The K order inside a 16-wide
+//     group is permuted (slot kq, step s  <->  k = 4*kq + s) identically for A and B, which is free for a
+//     sum and lets one 16-byte load feed four MFMA steps.
+//   * Two fragment patterns per operand:
+//       FRAG_K  (source contiguous along K):   one float4 (or uchar4) per tile  = 4 k-steps of that tile
+//       FRAG_MN (source contiguous along M/N): one vector per k-step            = V tiles (row/col = V*i + c)
+//     forward = (A FRAG_K patches, B FRAG_MN weights), dgrad = (FRAG_K, FRAG_K on W^T taps),
+//     wgrad = (FRAG_MN patches^T, FRAG_MN dY).
+//   * A is never materialised: patches are gathered through a compile-time geometry (u8 frames for conv1 with
+//     the 1/255 scale fused, fp32 NHWC otherwise; zero padding and stride-2 parity classes for dgrad).
+//   * Latency is hidden by a register ring PF groups deep and by splitting K over the WK waves of a workgroup
+//     (partials summed through LDS once, in the epilogue) and over blockIdx.z (split-K slabs reduced by the
+//     consumer) -- that is what fills 256 CUs when M is 32.
+//   * Epilogues: bias+ReLU, raw split-K slab (+ bias-gradient row for wgrad), ReLU-mask (dgrad) with the
+//     stride-2 parity scatter.
+#pragma once
+#include "common.h"
+
+namespace paac {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int IH_, int IW_, int C_, int OH_, int OW_, int S_, int PH_, int PW_, int KH_, int KW_>
+struct Geom {
+  static constexpr int IH = IH_, IW = IW_, C = C_, OH = OH_, OW = OW_, S = S_, PH = PH_, PW = PW_, KH = KH_, KW = KW_;
+  static constexpr int KWC = KW_ * C_;
+  static constexpr int FEATS = KH_ * KW_ * C_;
+  static constexpr int OPIX = OH_ * OW_;
+  static constexpr bool PADDED = (PH_ != 0) || (PW_ != 0);
+};
+
+enum { FRAG_K = 0, FRAG_MN = 1 };
+enum { EPI_BIAS_RELU = 0, EPI_SLAB = 1, EPI_MASK = 2, EPI_MASK_PARITY = 3 };
+
+struct GemmArgs {
+  const void* A;
+  const float* B;
+  float* out;
+  const float* aux;       // bias (EPI_BIAS_RELU) | activation the ReLU mask is derived from (EPI_MASK*)
+  int M, N, K;
+  int ldb;                // FRAG_MN B: row stride
+  int ldo;
+  int groups_per_part;    // 16-wide K groups per (blockIdx.z, wk) part
+  int slab_rows;          // EPI_SLAB: rows per slab (M, or M+1 with the bias-gradient row)
+  int tapoff[4][9];       // FRAG_K B: element offset of each (parity, tap)
+#ifdef PAAC_DMM_STAMPS
+  unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave
+#endif
+};
+
+#ifdef PAAC_DMM_STAMPS
+#define DMM_STAMP(i)                                                                          \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (p.stamps && lane == 0)                                                                \
+      p.stamps[((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NWM * NWN * WK) + wave) * 8 + (i)] = \
+          ((i) == 0 || (i) == 7) ? (unsigned long long)wall_clock64() : (unsigned long long)clock64();                          \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  } while (0)
+#else
+#define DMM_STAMP(i)
+#endif
+
+constexpr float kInputScale = 0.003921568859368563f;  // networks.py:115, float32(1/255)
+
+template <bool U8>
+__device__ __forceinline__ f32x4 load4(const void* base, long off) {
+  if constexpr (U8) {
+    const uchar4 v = *reinterpret_cast<const uchar4*>(static_cast<const uint8_t*>(base) + off);
+    return (f32x4){(float)v.x * kInputScale, (float)v.y * kInputScale, (float)v.z * kInputScale,
+                   (float)v.w * kInputScale};
+  } else {
+    return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + off);
+  }
+}
+
+template <int V>
+__device__ __forceinline__ f32x4 loadv(const float* p) {
+  if constexpr (V == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else if constexpr (V == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    return (f32x4){t.x, t.y, 0.f, 0.f};
+  } else {
+    return (f32x4){p[0], 0.f, 0.f, 0.f};
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void storev(float* p, const f32x4 v) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else if constexpr (V == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+    p[0] = v[0];
+  }
+}
+
+// AP/BP: fragment pattern of A / B.  TM/TN: 16x16 tiles per wave (for a FRAG_MN side this is also the vector
+// width V in {1,2,4}).  NWM x NWN x WK waves per workgroup.  BCO: channels per tap of a FRAG_K B operand.
+template <class G, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI, bool BIASROW,
+          int PF>
+__global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs p) {
+  static_assert(AP == FRAG_K || TM == 1 || TM == 2 || TM == 4, "FRAG_MN A: TM is the vector width");
+  static_assert(BP == FRAG_K || TN == 1 || TN == 2 || TN == 4, "FRAG_MN B: TN is the vector width");
+  static_assert(!BIASROW || (BP == FRAG_MN && NWM == 1), "bias row needs dY as a FRAG_MN B operand and one M-wave");
+  constexpr int NA = (AP == FRAG_K) ? TM : 4;
+  constexpr int NB = (BP == FRAG_K) ? TN : 4;
+  constexpr int RING = PF + 1;
+  constexpr int T = TM * TN;
+  constexpr int LDS_F4 = (WK > 1) ? (NWM * NWN * WK * T * 64) : 1;
+  __shared__ f32x4 red[LDS_F4 + (BIASROW ? NWN * WK * 16 : 0)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wk = wave % WK;
+  const int wn = (wave / WK) % NWN;
+  const int wm = wave / (WK * NWN);
+  const int li = lane & 15;   // row / column inside a tile
+  const int kq = lane >> 4;   // k-slot
+  const int z = blockIdx.z;
+  const int m0 = (blockIdx.x * NWM + wm) * (TM * 16);
+  const int n0 = (blockIdx.y * NWN + wn) * (TN * 16);
+  const int par = (EPI == EPI_MASK_PARITY) ? z : 0;
+  DMM_STAMP(0);
+  DMM_STAMP(1);
+
+  // ---- per-lane invariants ------------------------------------------------------------------------
+  // FRAG_K A: TM patch rows fixed for the whole loop
+  long a_base[(AP == FRAG_K) ? TM : 1];
+  int a_iy0[(AP == FRAG_K) ? TM : 1], a_ix0[(AP == FRAG_K) ? TM : 1];
+  bool a_ok[(AP == FRAG_K) ? TM : 1];
+  // FRAG_MN A (wgrad): the lane's TM consecutive features are fixed, rows move
+  int f_kh = 0, f_kwc = 0, f_kw = 0;
+  bool f_ok = false;
+  if constexpr (AP == FRAG_K) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int row = m0 + t * 16 + li;
+      a_ok[t] = row < p.M;
+      const int r = a_ok[t] ? row : 0;
+      const int b = r / G::OPIX;
+      const int rem = r - b * G::OPIX;
+      const int oy = rem / G::OW;
+      const int ox = rem - oy * G::OW;
+      a_iy0[t] = oy * G::S - G::PH;
+      a_ix0[t] = ox * G::S - G::PW;
+      a_base[t] = ((long)(b * G::IH + a_iy0[t]) * G::IW + a_ix0[t]) * G::C + 4 * kq;
+    }
+  } else {
+    const int f = m0 + TM * li;
+    f_ok = f < p.M;
+    f_kh = f / G::KWC;
+    f_kwc = f - f_kh * G::KWC;
+    f_kw = f_kwc / G::C;
+  }
+  // FRAG_K B (dgrad): TN weight rows (output channels of the transposed conv) fixed
+  long b_base[(BP == FRAG_K) ? TN : 1];
+  bool b_ok[(BP == FRAG_K) ? TN : 1];
+  if constexpr (BP == FRAG_K) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int n = n0 + t * 16 + li;
+      b_ok[t] = n < p.N;
+      b_base[t] = (long)(b_ok[t] ? n : 0) * BCO + 4 * kq;
+    }
+  }
+  const bool bn_ok = (BP == FRAG_MN) ? (n0 + TN * li < p.N) : true;
+
+  // ---- fragment loads for K group `g` (k16 = 16 g) --------------------------------------------------
+  f32x4 fa[RING][NA], fb[RING][NB];
+  auto load_group = [&](int slot, int g) {
+    const int k16 = g * 16;
+    if constexpr (AP == FRAG_K) {
+      const int kh = k16 / G::KWC;               // wave-uniform
+      const int kwc = k16 - kh * G::KWC;
+      const long goff = (long)kh * (G::IW * G::C) + kwc;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        bool ok = a_ok[t];
+        if constexpr (G::PADDED) {
+          const int iy = a_iy0[t] + kh;
+          const int ix = a_ix0[t] + kwc / G::C;
+          ok = ok && (iy >= 0) && (iy < G::IH) && (ix >= 0) && (ix < G::IW);
+        }
+        fa[slot][t] = ok ? load4<U8>(p.A, a_base[t] + goff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int r = k16 + 4 * kq + s;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (f_ok && r < p.K) {
+          const int b = r / G::OPIX;
+          const int rem = r - b * G::OPIX;
+          const int oy = rem / G::OW;
+          const int ox = rem - oy * G::OW;
+          const int iy = oy * G::S - G::PH + f_kh;
+          const int ix0 = ox * G::S - G::PW;
+          bool ok = true;
+          if constexpr (G::PADDED) ok = (iy >= 0) && (iy < G::IH) && (ix0 + f_kw >= 0) && (ix0 + f_kw < G::IW);
+          if (ok) {
+            const long off = ((long)(b * G::IH + iy) * G::IW + ix0) * G::C + f_kwc;
+            if constexpr (U8) {
+              static_assert(!U8 || TM == 4, "u8 FRAG_MN loads are uchar4");
+              v = load4<true>(p.A, off);
+            } else {
+              v = loadv<TM>(static_cast<const float*>(p.A) + off);
+            }
+          }
+        }
+        fa[slot][s] = v;
+      }
+    }
+    if constexpr (BP == FRAG_K) {
+      const int tap = k16 / BCO;                 // wave-uniform
+      const int co = k16 - tap * BCO;
+      const long goff = (long)p.tapoff[par][tap] + co;
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        fb[slot][t] = b_ok[t] ? *reinterpret_cast<const f32x4*>(p.B + b_base[t] + goff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = k16 + 4 * kq + s;
+        fb[slot][s] = (bn_ok && k < p.K) ? loadv<TN>(p.B + (long)k * p.ldb + n0 + TN * li) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- K range of this wave -------------------------------------------------------------------------
+  const int ngroups = (p.K + 15) / 16;
+  const int part = ((EPI == EPI_SLAB) ? z : 0) * WK + wk;
+  const int g_begin = min(part * p.groups_per_part, ngroups);
+  const int g_end = min(g_begin + p.groups_per_part, ngroups);
+  const int ng = g_end - g_begin;
+
+  DMM_STAMP(2);
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (s < ng) load_group(s, g_begin + s);
+  DMM_STAMP(3);
+  for (int gb = 0; gb < ng; gb += RING) {
+#pragma unroll
+    for (int st = 0; st < RING; ++st) {
+      const int gi = gb + st;
+      if (gi < ng) {
+        if (gi + PF < ng) load_group((st + PF) % RING, g_begin + gi + PF);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = (AP == FRAG_K) ? fa[st][i][s] : fa[st][s][i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float bv = (BP == FRAG_K) ? fb[st][j][s] : fb[st][s][j];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+          }
+          if constexpr (BIASROW) bsum += fb[st][s];
+        }
+      }
+    }
+  }
+
+  DMM_STAMP(4);
+  // ---- sum the WK partials through LDS ----------------------------------------------------------------
+  const int grp = wm * NWN + wn;
+  if constexpr (WK > 1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[((grp * WK + wk) * T + t) * 64 + lane] = acc[t / TN][t % TN];
+    __syncthreads();
+  }
+
+  DMM_STAMP(5);
+  // ---- epilogue: unit = one row of tiles (tm), handled by wave wk == tm % WK ----------------------------
+  const int q = kq;  // D layout: row = 4*q + r, col = li
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if ((tm % WK) != wk) continue;
+    f32x4 c[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      if constexpr (WK > 1) {
+        f32x4 v = red[((grp * WK + 0) * T + tm * TN + tn) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < WK; ++w) v += red[((grp * WK + w) * T + tm * TN + tn) * 64 + lane];
+        c[tn] = v;
+      } else {
+        c[tn] = acc[tm][tn];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // global row of D element (tile tm, row 4q+r)
+      const int m = (AP == FRAG_K) ? (m0 + tm * 16 + 4 * q + r) : (m0 + TM * (4 * q + r) + tm);
+      if (m >= p.M) continue;
+      if constexpr (BP == FRAG_MN) {
+        const int n = n0 + TN * li;
+        if (n >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) v[tn] = c[tn][r];
+        if constexpr (EPI == EPI_BIAS_RELU) {
+          const f32x4 bb = loadv<TN>(p.aux + n);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) v[tn] = fmaxf(v[tn] + bb[tn], 0.f);
+          storev<TN>(p.out + (long)m * p.ldo + n, v);
+        } else {
+          static_assert(BP != FRAG_MN || EPI == EPI_BIAS_RELU || EPI == EPI_SLAB, "FRAG_MN B epilogues");
+          storev<TN>(p.out + ((long)z * p.slab_rows + m) * p.ldo + n, v);
+        }
+      } else {
+        long orow = m;
+        if constexpr (EPI == EPI_MASK_PARITY) {
+          const int b = m / G::OPIX;
+          const int rem = m - b * G::OPIX;
+          const int a = rem / G::OW;
+          const int cc = rem - a * G::OW;
+          orow = ((long)b * (2 * G::OH) + 2 * a + (z >> 1)) * (2 * G::OW) + 2 * cc + (z & 1);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n = n0 + tn * 16 + li;
+          if (n < p.N) {
+            const float act = p.aux[orow * p.ldo + n];
+            p.out[orow * p.ldo + n] = act > 0.f ? c[tn][r] : 0.f;
+          }
+        }
+      }
+    }
+  }
+
+  DMM_STAMP(6);
+  DMM_STAMP(7);
+  // ---- bias-gradient row: column sums of dY over this part's K range ------------------------------------
+  if constexpr (BIASROW) {
+    if (blockIdx.x == 0 && wm == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = bsum[c];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        bsum[c] = v;
+      }
+      f32x4* bred = red + LDS_F4;
+      if constexpr (WK > 1) {
+        if (kq == 0) bred[(wn * WK + wk) * 16 + li] = bsum;
+        __syncthreads();
+        if (wk == 0 && kq == 0) {
+          f32x4 v = bred[(wn * WK) * 16 + li];
+#pragma unroll
+          for (int w = 1; w < WK; ++w) v += bred[(wn * WK + w) * 16 + li];
+          bsum = v;
+        }
+      }
+      if (wk == 0 && kq == 0 && n0 + TN * li < p.N)
+        storev<TN>(p.out + ((long)z * p.slab_rows + p.M) * p.ldo + n0 + TN * li, bsum);
+    }
+  }
+}
+
+template <class G, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI, bool BIASROW,
+          int PF>
+inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, hipStream_t s) {
+  const int ngroups = (a.K + 15) / 16;
+  const int parts = WK * ((EPI == EPI_SLAB) ? ksplit_z : 1);
+  a.groups_per_part = (ngroups + parts - 1) / parts;
+  dim3 grid((a.M + NWM * TM * 16 - 1) / (NWM * TM * 16), (a.N + NWN * TN * 16 - 1) / (NWN * TN * 16), zdim);
+  hipLaunchKernelGGL((dmm_kernel<G, U8, AP, BP, TM, TN, NWM, NWN, WK, BCO, EPI, BIASROW, PF>), grid,
+                     dim3(64 * NWM * NWN * WK), 0, s, a);
+}
+
+}  // namespace paac

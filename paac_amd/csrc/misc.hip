@@ -11,12 +11,17 @@ __global__ void nstep_returns_kernel(const float* __restrict__ v_boot, const flo
                                      double gamma, float* __restrict__ y, float* __restrict__ adv) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
-  double R = (double)v_boot[e];
+  // paac.py:146-147 as numpy evaluates it: estimated_return starts as the FLOAT32 network output, so the first
+  // `gamma * estimated_return` is a float32 product (python float x float32 array -> float32, in numpy 1.x
+  // and 2.x alike); it is promoted to float64 by `* masks[t]` and stays float64 afterwards.  Explicit
+  // round-to-nearest mul/add (no FMA contraction) keep the scan bit-identical to numpy's.
+  double R = 0.0;
   for (int t = T - 1; t >= 0; --t) {
     const long i = (long)t * N + e;
-    R = (double)rewards[i] + gamma * R * (double)masks[i];
+    const double prod = (t == T - 1) ? (double)__fmul_rn((float)gamma, v_boot[e]) : __dmul_rn(gamma, R);
+    R = __dadd_rn((double)rewards[i], __dmul_rn(prod, (double)masks[i]));
     y[i] = (float)R;
-    adv[i] = (float)(R - (double)values[i]);
+    adv[i] = (float)__dsub_rn(R, (double)values[i]);
   }
 }
 
@@ -30,6 +35,13 @@ __global__ void lr_step_kernel(int64_t* global_step, int64_t inc, double lr0, in
 }
 
 __global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
+
+// Diagnostic: {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)} -- the quotient of two
+// samples' differences is the shader clock the chip actually held in between.
+__global__ void clock_probe_kernel(uint64_t* out) {
+  out[0] = (uint64_t)clock64();
+  out[1] = (uint64_t)wall_clock64();
+}
 
 // =============================================================================================
 // Philox4x32-10 throughput sampler (oracle/sampler.py:sample_philox).
@@ -85,10 +97,20 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
 }
 
 // scratch layout (bytes): pj f64[N*(A-1)] | U f64[N*(A-1)] | blocks u32[nblk*624]
+// LDSPATH (N*(A-1) <= 1024): the three work arrays live in LDS instead of the global scratch.
+constexpr int MT_LDS_D = 1024;
+constexpr int MT_LDS_BLK = 5;   // 624 + 2*1024 u32 <= 5*624
+template <bool LDSPATH>
 __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict__ probs, int N, int A,
-                                                        uint32_t* __restrict__ mt_state, double* __restrict__ pj_buf,
-                                                        double* __restrict__ u_buf, uint32_t* __restrict__ blocks,
+                                                        uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
+                                                        double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
                                                         int32_t* __restrict__ actions) {
+  __shared__ double pj_s[LDSPATH ? MT_LDS_D : 1];
+  __shared__ double u_s[LDSPATH ? MT_LDS_D : 1];
+  __shared__ uint32_t blocks_s[LDSPATH ? MT_LDS_BLK * 624 : 1];
+  double* pj_buf = LDSPATH ? pj_s : pj_g;
+  double* u_buf = LDSPATH ? u_s : u_g;
+  uint32_t* blocks = LDSPATH ? blocks_s : blocks_g;
   const int tid = threadIdx.x;
   const int J = A - 1;
   const int D = N * J;
@@ -115,6 +137,7 @@ __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict_
     for (int k = 227 + tid; k < 454; k += 256) nw[k] = nw[k - 227] ^ mt_mix(o[k], o[k + 1]);
     __syncthreads();
     for (int k = 454 + tid; k < 623; k += 256) nw[k] = nw[k - 227] ^ mt_mix(o[k], o[k + 1]);
+    __syncthreads();
     if (tid == 0) nw[623] = nw[396] ^ mt_mix(o[623], nw[0]);
     __syncthreads();
   }
@@ -459,6 +482,12 @@ int paac_counter_add(uint64_t* counter_dev, uint64_t inc, paac_stream_t stream) 
   return 0;
 }
 
+int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream) {
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out2_dev);
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int paac_sample_philox(const float* probs, int N, int A, uint64_t seed, const uint64_t* step_base_dev,
                        uint64_t step_offset, uint32_t env_offset, int32_t* actions, paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_philox: N=%d A=%d", N, A);
@@ -482,8 +511,12 @@ int paac_sample_mt(const float* probs, int N, int A, uint32_t* mt_state, void* s
   double* pj = (double*)scratch;
   double* u = pj + D;
   uint32_t* blocks = (uint32_t*)(u + D);
-  hipLaunchKernelGGL(sample_mt_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, N, A, mt_state, pj, u, blocks,
-                     actions);
+  if (D <= MT_LDS_D)
+    hipLaunchKernelGGL((sample_mt_kernel<true>), dim3(1), dim3(256), 0, (hipStream_t)stream, probs, N, A, mt_state, pj,
+                       u, blocks, actions);
+  else
+    hipLaunchKernelGGL((sample_mt_kernel<false>), dim3(1), dim3(256), 0, (hipStream_t)stream, probs, N, A, mt_state, pj,
+                       u, blocks, actions);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -560,7 +593,7 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   PAAC_REQUIRE(clip_mode == PAAC_CLIP_IGNORE || clip_mode == PAAC_CLIP_GLOBAL,
                "paac_clip_rmsprop: clip mode %d (the reference's 'local' branch is undefined)", clip_mode);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(ctx, F_CLIP_RMSPROP, s);
+  ProfScope ps(ctx, F_CLIP_RMSPROP, (int)(n / 4), s);
   const long n4 = n / 4;
   hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grad, n4, grad_scale, ctx->partials);
   hipLaunchKernelGGL(rmsprop_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, params, grad, ms, mom, n4, lr_dev, decay,

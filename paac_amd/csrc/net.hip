@@ -3,7 +3,7 @@
 //   optimizer.compute_gradients(loss) builds from them (actor_learner.py:44).
 // Layout contract: activations NHWC fp32, conv weights HWIO, fc weights [in,out], flatten in HWC order
 // (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
-#include "igemm.h"
+#include "dmm.h"
 
 namespace paac {
 
@@ -34,39 +34,116 @@ constexpr int FC_SPLITS_MAX = 16;
 constexpr int W_SPLITS_MAX = 64;
 constexpr int MAXA = 32;
 
-// Tile-config dispatch by the GEMM's compile-time N and the grid it would produce.
-template <class G, bool U8, int AM, int BMo, int BCO, int EPI, bool BR, int NDIM>
-static void launch_auto(const GemmArgs& a, int zdim, hipStream_t s) {
-  if constexpr (NDIM % 32 != 0) {
-    launch_igemm<G, U8, AM, BMo, BCO, EPI, BR, 64, 16, 4, 1, 1>(a, zdim, s);
-  } else {
-    constexpr int BNBIG = (NDIM % 64 == 0) ? 64 : 32;
-    const long big_blocks = (long)((a.M + 63) / 64) * ((a.N + BNBIG - 1) / BNBIG) * zdim;
-    if (big_blocks < 256) {
-      launch_igemm<G, U8, AM, BMo, BCO, EPI, BR, 32, 32, 1, 1, 4>(a, zdim, s);
-    } else if constexpr (NDIM % 64 == 0) {
-      launch_igemm<G, U8, AM, BMo, BCO, EPI, BR, 64, 64, 2, 2, 1>(a, zdim, s);
-    } else {
-      launch_igemm<G, U8, AM, BMo, BCO, EPI, BR, 64, 32, 2, 1, 2>(a, zdim, s);
-    }
-  }
+#ifdef PAAC_DMM_STAMPS
+unsigned long long* g_stamps = nullptr;   // diagnostic build: the `which`-th dmm launch after the call is stamped
+int g_stamp_which = -1, g_stamp_calls = 0;
+extern "C" void paac_debug_set_stamps(unsigned long long* p, int which) {
+  g_stamps = p;
+  g_stamp_which = which;
+  g_stamp_calls = 0;
 }
+#endif
 
-static GemmArgs make_args(const void* A, const float* B, float* out, const float* aux, int M, int N, int K, int a_rows,
-                          int ldb, int ldo) {
+static GemmArgs make_args(const void* A, const float* B, float* out, const float* aux, int M, int N, int K, int ldb,
+                          int ldo) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.out = out; g.aux = aux;
-  g.M = M; g.N = N; g.K = K; g.a_rows = a_rows; g.ldb = ldb; g.ldo = ldo;
-  g.chunks_per_split = (K + 31) / 32;
+  g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldo = ldo;
   g.slab_rows = M;
+#ifdef PAAC_DMM_STAMPS
+  g.stamps = (g_stamp_calls++ == g_stamp_which) ? g_stamps : nullptr;
+#endif
   return g;
 }
 
+// blockIdx.z split of K so that the launch has about `target_waves` waves.
+static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int target_waves = 1024) {
+  long s = (target_waves + tiles * wk - 1) / (tiles * wk);
+  if (s > max_split) s = max_split;
+  if (s > ngroups / wk) s = ngroups / wk;
+  if (s < 1) s = 1;
+  const int per = (int)((ngroups + s * wk - 1) / (s * wk));     // groups per (z, wk) part
+  s = (ngroups + (long)per * wk - 1) / ((long)per * wk);         // drop empty tail slabs
+  return (int)s;
+}
+
+// Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
+template <class G, bool U8, int NDIM, int EPI>
+static void launch_fwd(const GemmArgs& g, int ksplit, hipStream_t s) {
+  constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+  const long rows16 = (g.M + 15) / 16;
+  const long ncol = (g.N + 16 * VN - 1) / (16 * VN);
+  if (rows16 * ncol * ksplit <= 256) {
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 1, VN, 1, 1, 8, 1, EPI, false, 5>(g, ksplit, ksplit, s);   // 16 rows, K over 8 waves
+  } else if (rows16 * ncol * ksplit <= 1024) {
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 1, 1, 4, 1, EPI, false, 4>(g, ksplit, ksplit, s);   // 32 rows, K over 4 waves
+  } else if (rows16 * ncol * ksplit <= 4096) {
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 2, 1, 2, 1, EPI, false, 4>(g, ksplit, ksplit, s);   // 64 rows, K over 2 waves
+  } else {
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 4, 1, 1, 1, EPI, false, 4>(g, ksplit, ksplit, s);   // 128 rows, no K split
+  }
+}
+
+// dgrad: A = FRAG_K patches of dY, B = FRAG_K taps of W^T.
+template <class G, int NDIM, int BCO, int EPI>
+static void launch_dgrad(const GemmArgs& g, int zdim, hipStream_t s) {
+  constexpr int TN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+  const long tiles = (long)((g.M + 31) / 32) * ((g.N + 16 * TN - 1) / (16 * TN)) * zdim;
+  if (tiles <= 384) {
+    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 1, 1, 4, BCO, EPI, false, 4>(g, zdim, 1, s);
+  } else if (tiles <= 1536) {
+    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 2, 1, 2, BCO, EPI, false, 4>(g, zdim, 1, s);
+  } else {
+    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 4, 1, 1, BCO, EPI, false, 4>(g, zdim, 1, s);
+  }
+}
+
+// wgrad: A = FRAG_MN patches^T (64 features per wave), B = FRAG_MN dY; split-K slabs + bias-gradient row.
+template <class G, bool U8, int NDIM>
+static int launch_wgrad(GemmArgs g, int max_split, hipStream_t s) {
+  constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+  const long tiles = (long)((g.M + 63) / 64) * ((g.N + 16 * VN - 1) / (16 * VN));
+  const int ngroups = (g.K + 15) / 16;
+  if (ngroups >= 32) {
+    const int ks = pick_ksplit(tiles, 4, ngroups, max_split);
+    launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 4, 1, EPI_SLAB, true, 3>(g, ks, ks, s);
+    return ks;
+  }
+  const int ks = 1;
+  launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 2, 1, EPI_SLAB, true, 3>(g, ks, ks, s);
+  return ks;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Heads forward: h = relu(sum of fc split-K slabs + b); logits = h Wa + ba; pi = softmax; v = h Wc + bc.
-// policy_v_network.py:24-26,37 / networks.py:84-89.  One 256-thread workgroup per batch row;
-// wavefront shuffles for the A+1 dot-product reductions.
+// Heads forward: h = relu(sum of fc split-K slabs + b); logits = h Wa + ba; pi = softmax; v = h Wc + bc
+// (policy_v_network.py:24-26,37 / networks.py:84-89), optionally followed by the counter-based categorical
+// sampler (wavefront-level: one row per workgroup, shuffles for the A+1 dot products).
+struct PhiloxArgs {
+  int enabled;
+  uint64_t seed;
+  const uint64_t* step_base;
+  uint64_t step_off;
+  uint32_t env_offset;
+  int32_t* actions;
+};
+
+__device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
 template <int H>
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ slab, int splits, long slab_stride,
                                                         const float* __restrict__ fc_b, const float* __restrict__ Wa,
@@ -74,15 +151,23 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ bc, int A, float* __restrict__ h_out,
                                                         float* __restrict__ logits_ws, float* __restrict__ probs_ws,
                                                         float* __restrict__ values_ws, float* __restrict__ logits_out,
-                                                        float* __restrict__ probs_out, float* __restrict__ values_out) {
+                                                        float* __restrict__ probs_out, float* __restrict__ values_out,
+                                                        const PhiloxArgs ph) {
   const int i = blockIdx.x;
   const int tid = threadIdx.x;
   float part[MAXA + 1];
 #pragma unroll
   for (int a = 0; a <= MAXA; ++a) part[a] = 0.f;
-  for (int j = tid; j < H; j += 256) {
+  constexpr int JPT = H / 256;
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int j = tid + jj * 256;
+    float sv[FC_SPLITS_MAX];
+#pragma unroll
+    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) sv[sp] = (sp < splits) ? slab[sp * slab_stride + (long)i * H + j] : 0.f;
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += slab[sp * slab_stride + (long)i * H + j];
+#pragma unroll
+    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) s += sv[sp];
     s = fmaxf(s + fc_b[j], 0.f);
     h_out[(long)i * H + j] = s;
 #pragma unroll
@@ -119,6 +204,16 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         e[a] = expf(lg[a] - m);
         sum += e[a];
       }
+    float u = 0.f;
+    if (ph.enabled) {
+      const uint64_t step = (ph.step_base ? *ph.step_base : 0ull) + ph.step_off;
+      const uint32_t w = philox_word0(ph.env_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32), 0u,
+                                      (uint32_t)ph.seed, (uint32_t)(ph.seed >> 32));
+      u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    }
+    int act = A - 1;
+    bool found = false;
+    float cum = 0.f;
 #pragma unroll
     for (int a = 0; a < MAXA; ++a)
       if (a < A) {
@@ -127,9 +222,17 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         logits_ws[(long)i * A + a] = lg[a];
         if (probs_out) probs_out[(long)i * A + a] = pa;
         if (logits_out) logits_out[(long)i * A + a] = lg[a];
+        if (a < A - 1) {
+          cum += pa;
+          if (!found && u < cum) {
+            act = a;
+            found = true;
+          }
+        }
       }
     values_ws[i] = lg[MAXA];
     if (values_out) values_out[i] = lg[MAXA];
+    if (ph.enabled) ph.actions[i] = act;
   }
 }
 
@@ -166,9 +269,11 @@ __device__ __forceinline__ void head_grad_row(const float* __restrict__ pi, floa
 }
 
 // One launch, three roles by blockIdx:
-//   [0, B)            : row i -> dH[i,:] = (dlogits Wa^T + dv Wc^T) * 1[h > 0]
-//   [B, B + H/256)    : head weight gradients dWa[j,:], dWc[j] for 256 values of j (loops over rows)
-//   B + H/256         : head bias gradients + loss scalars
+//   [0, B)              : row i -> dH[i,:] = (dlogits Wa^T + dv Wc^T) * 1[h > 0]
+//   [B, B + H/32)       : head weight gradients for 32 values of j: 8 row-groups x 32 columns per workgroup,
+//                         dlogits recomputed into LDS in chunks of 256 rows
+//   B + H/32            : head bias gradients + loss scalars
+constexpr int HB_CHUNK = 256;
 template <int H>
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ values,
                                                         const int32_t* __restrict__ actions, const float* __restrict__ y,
@@ -180,7 +285,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ loss_out) {
   const int tid = threadIdx.x;
   const float s = 5.0f / (float)B;
-  __shared__ float sdl[64][MAXA + 1];
+  __shared__ float sdl[HB_CHUNK][MAXA + 1];
   if ((int)blockIdx.x < B) {
     const int i = blockIdx.x;
     if (tid == 0) {
@@ -200,14 +305,15 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     return;
   }
   const int role = blockIdx.x - B;
-  if (role < H / 256) {
-    const int j = role * 256 + tid;
+  if (role < H / 32) {
+    const int jj = tid & 31, ig = tid >> 5;
+    const int j = role * 32 + jj;
     float acc[MAXA + 1];
 #pragma unroll
     for (int a = 0; a <= MAXA; ++a) acc[a] = 0.f;
-    for (int i0 = 0; i0 < B; i0 += 64) {
+    for (int i0 = 0; i0 < B; i0 += HB_CHUNK) {
       __syncthreads();
-      if (tid < 64 && i0 + tid < B) {
+      if (i0 + tid < B) {
         const int i = i0 + tid;
         float dl[MAXA], dv;
         head_grad_row(probs + (long)i * A, values[i], actions[i], y[i], adv[i], beta, s, A, dl, &dv, nullptr);
@@ -217,8 +323,9 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         sdl[tid][MAXA] = dv;
       }
       __syncthreads();
-      const int cnt = min(64, B - i0);
-      for (int r = 0; r < cnt; ++r) {
+      const int cnt = min(HB_CHUNK, B - i0);
+#pragma unroll 4
+      for (int r = ig; r < cnt; r += 8) {
         const float hv = h[(long)(i0 + r) * H + j];
 #pragma unroll
         for (int a = 0; a < MAXA; ++a)
@@ -226,10 +333,24 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         acc[MAXA] += hv * sdl[r][MAXA];
       }
     }
+    __syncthreads();
+    // reduce the 8 row-groups through LDS (reuse sdl: [8][32][MAXA+1] floats = 8448 <= 256*33)
+    float* redw = &sdl[0][0];
 #pragma unroll
-    for (int a = 0; a < MAXA; ++a)
-      if (a < A) gWa[j * A + a] = acc[a];
-    gWc[j] = acc[MAXA];
+    for (int a = 0; a <= MAXA; ++a)
+      if (a < A || a == MAXA) redw[(ig * 32 + jj) * (MAXA + 1) + a] = acc[a];
+    __syncthreads();
+    for (int u = tid; u < 32 * (MAXA + 1); u += 256) {
+      const int c = u / (MAXA + 1), a = u % (MAXA + 1);
+      if (a < A || a == MAXA) {
+        float v = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) v += redw[(g8 * 32 + c) * (MAXA + 1) + a];
+        const int jo = role * 32 + c;
+        if (a == MAXA) gWc[jo] = v;
+        else gWa[jo * A + a] = v;
+      }
+    }
     return;
   }
   // bias gradients + loss scalars
@@ -276,7 +397,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-K slab reduction into the flat gradient (deterministic: fixed summation order).
+// Split-K slab reduction into the flat gradient (deterministic: fixed summation order, 8 loads in flight).
 struct FinalizeSeg {
   const float* src;  // first slab
   float* dst;
@@ -292,22 +413,23 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinalizeArgs a
   const FinalizeSeg sg = a.seg[blockIdx.y];
   const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= sg.count) return;
-  float4 v = *reinterpret_cast<const float4*>(sg.src + i);
-  for (int s = 1; s < sg.splits; ++s) {
-    const float4 t = *reinterpret_cast<const float4*>(sg.src + s * sg.stride + i);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < sg.splits; s0 += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      t[u] = (s0 + u < sg.splits) ? *reinterpret_cast<const f32x4*>(sg.src + (long)(s0 + u) * sg.stride + i)
+                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
   }
-  *reinterpret_cast<float4*>(sg.dst + i) = v;
+  *reinterpret_cast<f32x4*>(sg.dst + i) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
-static int tensor_index(const paac_ctx* ctx, int which /*0 conv1 .. fc, actor, critic*/, bool bias) {
-  return which * 2 + (bias ? 1 : 0);
-}
-
 template <class NT>
 static int forward_impl(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* logits,
-                        float* probs, float* values, hipStream_t s) {
+                        float* probs, float* values, const PhiloxArgs& ph, hipStream_t s) {
   const paac_layout& L = ctx->layout;
   const int A = ctx->cfg.num_actions;
   int t = 0;
@@ -329,57 +451,38 @@ static int forward_impl(paac_ctx* ctx, const float* params, const uint8_t* state
   const float* bc = params + L.offset[t++];
 
   {
-    ProfScope ps(ctx, F_CONV1_FWD, s);
-    GemmArgs g = make_args(states, w1, ctx->act[0], b1, batch * 400, NT::C1, 256, batch * 400, NT::C1, NT::C1);
-    launch_auto<typename NT::G1, true, A_ROWS_M, B_KN, 1, EPI_BIAS_RELU, false, NT::C1>(g, 1, s);
+    ProfScope ps(ctx, F_CONV1_FWD, batch, s);
+    GemmArgs g = make_args(states, w1, ctx->act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
+    launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, 1, s);
   }
   {
-    ProfScope ps(ctx, F_CONV2_FWD, s);
-    GemmArgs g = make_args(ctx->act[0], w2, ctx->act[1], b2, batch * 81, NT::C2, 16 * NT::C1, batch * 81, NT::C2, NT::C2);
-    launch_auto<typename NT::G2, false, A_ROWS_M, B_KN, 1, EPI_BIAS_RELU, false, NT::C2>(g, 1, s);
+    ProfScope ps(ctx, F_CONV2_FWD, batch, s);
+    GemmArgs g = make_args(ctx->act[0], w2, ctx->act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
+    launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, 1, s);
   }
   const float* last = ctx->act[1];
   if constexpr (NT::NCONV == 3) {
-    ProfScope ps(ctx, F_CONV3_FWD, s);
-    GemmArgs g = make_args(ctx->act[1], w3, ctx->act[2], b3, batch * 49, NT::C3, 9 * NT::C2, batch * 49, NT::C3, NT::C3);
-    launch_auto<typename NT::G3, false, A_ROWS_M, B_KN, 1, EPI_BIAS_RELU, false, NT::C3>(g, 1, s);
+    ProfScope ps(ctx, F_CONV3_FWD, batch, s);
+    GemmArgs g = make_args(ctx->act[1], w3, ctx->act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
+    launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, 1, s);
     last = ctx->act[2];
   }
   int splits = 1;
   {
-    ProfScope ps(ctx, F_FC_FWD, s);
-    GemmArgs g = make_args(last, wf, ctx->fc_slab, nullptr, batch, NT::H, NT::FLAT, batch, NT::H, NT::H);
-    const int chunks = (NT::FLAT + 31) / 32;
-    if (batch < 512) {
-      const int tiles = ((batch + 31) / 32) * (NT::H / 32);
-      splits = (256 + tiles - 1) / tiles;
-      if (splits > FC_SPLITS_MAX) splits = FC_SPLITS_MAX;
-      if (splits < 1) splits = 1;
-    }
-    int cps = (chunks + splits - 1) / splits;
-    splits = (chunks + cps - 1) / cps;
-    g.chunks_per_split = cps;
+    ProfScope ps(ctx, F_FC_FWD, batch, s);
+    GemmArgs g = make_args(last, wf, ctx->fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
+    const long tiles = (long)((batch + 15) / 16) * (NT::H / 64);
+    splits = pick_ksplit(tiles, 4, NT::FLAT / 16, FC_SPLITS_MAX, 768);
     g.slab_rows = batch;
-    launch_auto<typename NT::GFC, false, A_ROWS_M, B_KN, 1, EPI_SLAB, false, NT::H>(g, splits, s);
+    launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, splits, s);
   }
   {
-    ProfScope ps(ctx, F_HEADS_FWD, s);
+    ProfScope ps(ctx, F_HEADS_FWD, batch, s);
     hipLaunchKernelGGL((heads_fwd_kernel<NT::H>), dim3(batch), dim3(256), 0, s, ctx->fc_slab, splits,
                        (long)batch * NT::H, bf, wa, ba, wc, bc, A, ctx->h, ctx->logits, ctx->probs, ctx->values, logits,
-                       probs, values);
+                       probs, values, ph);
   }
   return 0;
-}
-
-static void split_plan(int tiles, int chunks, int max_splits, int* splits, int* cps) {
-  int s = (320 + tiles - 1) / tiles;
-  if (s > max_splits) s = max_splits;
-  if (s > chunks) s = chunks;
-  if (s < 1) s = 1;
-  int c = (chunks + s - 1) / s;
-  s = (chunks + c - 1) / c;
-  *splits = s;
-  *cps = c;
 }
 
 template <class NT>
@@ -388,12 +491,9 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
                          hipStream_t s) {
   const paac_layout& L = ctx->layout;
   const int A = ctx->cfg.num_actions;
-  const int nt = L.num_tensors;
-  // tensor indices
   const int i_w1 = 0, i_w2 = 2, i_w3 = 4;
   const int i_wf = (NT::NCONV == 3) ? 6 : 4;
   const int i_wa = i_wf + 2, i_wc = i_wf + 4;
-  (void)nt;
   const float* wa = params + L.offset[i_wa];
   const float* wc = params + L.offset[i_wc];
   const float* wf = params + L.offset[i_wf];
@@ -402,111 +502,90 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
 
   // (1) heads: dH, head weight/bias grads, loss scalars
   {
-    ProfScope ps(ctx, F_HEADS_BWD, s);
-    hipLaunchKernelGGL((heads_bwd_kernel<NT::H>), dim3(batch + NT::H / 256 + 1), dim3(256), 0, s, ctx->probs,
+    ProfScope ps(ctx, F_HEADS_BWD, batch, s);
+    hipLaunchKernelGGL((heads_bwd_kernel<NT::H>), dim3(batch + NT::H / 32 + 1), dim3(256), 0, s, ctx->probs,
                        ctx->values, actions, y, adv, ctx->h, wa, wc, A, batch, beta, ctx->dh, grad + L.offset[i_wa],
                        grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out);
   }
   const float* xf = (NT::NCONV == 3) ? ctx->act[2] : ctx->act[1];   // flattened last conv output
   float* dxf = (NT::NCONV == 3) ? ctx->dact[2] : ctx->dact[1];
-  // (2) fc wgrad (+ bias row) straight into the flat gradient: [FLAT+1][H] = fc_w then fc_b
-  {
-    ProfScope ps(ctx, F_FC_WGRAD, s);
-    GemmArgs g = make_args(xf, ctx->dh, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, batch, NT::H, NT::H);
-    g.slab_rows = NT::FLAT + 1;
-    launch_auto<typename NT::GFC, false, A_ROWS_K, B_KN, 1, EPI_SLAB, true, NT::H>(g, 1, s);
-  }
-  // (3) fc dgrad, masked by relu'(last conv output)
-  {
-    ProfScope ps(ctx, F_FC_DGRAD, s);
-    GemmArgs g = make_args(ctx->dh, wf, dxf, xf, batch, NT::FLAT, NT::H, batch, 0, NT::FLAT);
-    g.tapoff[0][0] = 0;
-    launch_auto<typename NT::GFCH, false, A_ROWS_M, B_NK_TAPS, NT::H, EPI_MASK, false, NT::FLAT>(g, 1, s);
-  }
   FinalizeArgs fin;
   memset(&fin, 0, sizeof(fin));
   float* slab = ctx->wslab;
-  auto add_segments = [&](int i_w, int feats, int cout, int splits, float* base) {
-    if (splits <= 1) return;
+  // conv wgrads write split-K slabs (+ bias row) into the workspace; grad_finalize_kernel sums them into the
+  // flat gradient in a fixed order (deterministic, unlike float atomics).
+  auto wgrad_out = [&](int i_w, int feats, int cout, float* base, int splits) {
     const long stride = (long)(feats + 1) * cout;
     fin.seg[fin.nseg++] = FinalizeSeg{base, grad + L.offset[i_w], feats * cout, splits, stride};
     fin.seg[fin.nseg++] = FinalizeSeg{base + (long)feats * cout, grad + L.offset[i_w + 1], cout, splits, stride};
   };
+  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b
+  {
+    ProfScope ps(ctx, F_FC_WGRAD, batch, s);
+    GemmArgs g = make_args(xf, ctx->dh, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
+    g.slab_rows = NT::FLAT + 1;
+    launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, s);
+  }
+  // (3) fc dgrad, masked by relu'(last conv output)
+  {
+    ProfScope ps(ctx, F_FC_DGRAD, batch, s);
+    GemmArgs g = make_args(ctx->dh, wf, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
+    g.tapoff[0][0] = 0;
+    launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, s);
+  }
   if constexpr (NT::NCONV == 3) {
-    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3, split-K slabs
-    int splits, cps;
+    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3
     {
-      ProfScope ps(ctx, F_CONV_WGRAD, s);
+      ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
       const int feats = NT::G3::FEATS;
-      GemmArgs g = make_args(ctx->act[1], ctx->dact[2], nullptr, nullptr, feats, NT::C3, batch * 49, batch * 49, NT::C3, NT::C3);
-      split_plan(((feats + 63) / 64) * ((NT::C3 + 63) / 64), (batch * 49 + 31) / 32, W_SPLITS_MAX, &splits, &cps);
-      g.chunks_per_split = cps;
+      GemmArgs g = make_args(ctx->act[1], ctx->dact[2], slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
       g.slab_rows = feats + 1;
-      g.out = (splits > 1) ? slab : grad + L.offset[i_w3];
-      launch_igemm<typename NT::G3, false, A_ROWS_K, B_KN, 1, EPI_SLAB, true, 64, 64, 2, 2, 1>(g, splits, s);
-      add_segments(i_w3, feats, NT::C3, splits, slab);
+      const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, s);
+      wgrad_out(i_w3, feats, NT::C3, slab, splits);
       slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
     }
     // (5) conv3 dgrad -> dact[1] masked by relu'(a2)
     {
-      ProfScope ps(ctx, F_CONV_DGRAD, s);
-      GemmArgs g = make_args(ctx->dact[2], w3, ctx->dact[1], ctx->act[1], batch * 81, NT::C2, 9 * NT::C3, batch * 81, 0, NT::C2);
+      ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
+      GemmArgs g = make_args(ctx->dact[2], w3, ctx->dact[1], ctx->act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
       for (int kh = 0; kh < 3; ++kh)
         for (int kw = 0; kw < 3; ++kw) g.tapoff[0][kh * 3 + kw] = ((2 - kh) * 3 + (2 - kw)) * NT::C2 * NT::C3;
-      launch_auto<typename NT::G3D, false, A_ROWS_M, B_NK_TAPS, NT::C3, EPI_MASK, false, NT::C2>(g, 1, s);
+      launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, s);
     }
   }
   // (6) conv2 wgrad
   {
-    int splits, cps;
-    ProfScope ps(ctx, F_CONV_WGRAD, s);
+    ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
     const int feats = NT::G2::FEATS;
-    GemmArgs g = make_args(ctx->act[0], ctx->dact[1], nullptr, nullptr, feats, NT::C2, batch * 81, batch * 81, NT::C2, NT::C2);
-    constexpr int BNW = (NT::C2 % 64 == 0) ? 64 : 32;
-    split_plan(((feats + 63) / 64) * ((NT::C2 + BNW - 1) / BNW), (batch * 81 + 31) / 32, W_SPLITS_MAX, &splits, &cps);
-    g.chunks_per_split = cps;
+    GemmArgs g = make_args(ctx->act[0], ctx->dact[1], slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
     g.slab_rows = feats + 1;
-    g.out = (splits > 1) ? slab : grad + L.offset[i_w2];
-    if constexpr (NT::C2 % 64 == 0)
-      launch_igemm<typename NT::G2, false, A_ROWS_K, B_KN, 1, EPI_SLAB, true, 64, 64, 2, 2, 1>(g, splits, s);
-    else
-      launch_igemm<typename NT::G2, false, A_ROWS_K, B_KN, 1, EPI_SLAB, true, 64, 32, 2, 1, 2>(g, splits, s);
-    add_segments(i_w2, feats, NT::C2, splits, slab);
+    const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, s);
+    wgrad_out(i_w2, feats, NT::C2, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C2;
   }
   // (7) conv2 dgrad by output parity (4 classes in blockIdx.z) -> dact[0] masked by relu'(a1)
   {
-    ProfScope ps(ctx, F_CONV_DGRAD, s);
-    GemmArgs g = make_args(ctx->dact[1], w2, ctx->dact[0], ctx->act[0], batch * 100, NT::C1, 4 * NT::C2, batch * 100, 0, NT::C1);
+    ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
+    GemmArgs g = make_args(ctx->dact[1], w2, ctx->dact[0], ctx->act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
     for (int par = 0; par < 4; ++par) {
       const int py = par >> 1, px = par & 1;
       for (int kh = 0; kh < 2; ++kh)
         for (int kw = 0; kw < 2; ++kw)
           g.tapoff[par][kh * 2 + kw] = ((py + 2 * (1 - kh)) * 4 + (px + 2 * (1 - kw))) * NT::C1 * NT::C2;
     }
-    if constexpr (NT::C1 % 32 == 0)
-      launch_igemm<typename NT::G2D, false, A_ROWS_M, B_NK_TAPS, NT::C2, EPI_MASK_PARITY, false, 64, 32, 2, 1, 2>(g, 4, s);
-    else
-      launch_igemm<typename NT::G2D, false, A_ROWS_M, B_NK_TAPS, NT::C2, EPI_MASK_PARITY, false, 64, 16, 4, 1, 1>(g, 4, s);
+    launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(g, 4, s);
   }
   // (8) conv1 wgrad from the u8 frames
   {
-    int splits, cps;
-    ProfScope ps(ctx, F_CONV1_WGRAD, s);
+    ProfScope ps(ctx, F_CONV1_WGRAD, batch, s);
     const int feats = 256;
-    GemmArgs g = make_args(states, ctx->dact[0], nullptr, nullptr, feats, NT::C1, batch * 400, batch * 400, NT::C1, NT::C1);
-    split_plan(4, (batch * 400 + 31) / 32, W_SPLITS_MAX, &splits, &cps);
-    g.chunks_per_split = cps;
+    GemmArgs g = make_args(states, ctx->dact[0], slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
     g.slab_rows = feats + 1;
-    g.out = (splits > 1) ? slab : grad + L.offset[i_w1];
-    if constexpr (NT::C1 % 32 == 0)
-      launch_igemm<typename NT::G1, true, A_ROWS_K, B_KN, 1, EPI_SLAB, true, 64, 32, 2, 1, 2>(g, splits, s);
-    else
-      launch_igemm<typename NT::G1, true, A_ROWS_K, B_KN, 1, EPI_SLAB, true, 64, 16, 4, 1, 1>(g, splits, s);
-    add_segments(i_w1, feats, NT::C1, splits, slab);
+    const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, s);
+    wgrad_out(i_w1, feats, NT::C1, slab, splits);
   }
-  if (fin.nseg > 0) {
-    ProfScope ps(ctx, F_GRAD_FINALIZE, s);
+  {
+    ProfScope ps(ctx, F_GRAD_FINALIZE, batch, s);
     int maxcount = 0;
     for (int i = 0; i < fin.nseg; ++i) maxcount = fin.seg[i].count > maxcount ? fin.seg[i].count : maxcount;
     hipLaunchKernelGGL(grad_finalize_kernel, dim3((maxcount / 4 + 255) / 256, fin.nseg), dim3(256), 0, s, fin);
@@ -516,8 +595,26 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
 
 int launch_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, bool, float* logits,
                    float* probs, float* values, hipStream_t s) {
-  if (ctx->cfg.arch == PAAC_ARCH_NATURE) return forward_impl<NatureNet>(ctx, params, states, batch, logits, probs, values, s);
-  return forward_impl<NipsNet>(ctx, params, states, batch, logits, probs, values, s);
+  PhiloxArgs ph;
+  memset(&ph, 0, sizeof(ph));
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    return forward_impl<NatureNet>(ctx, params, states, batch, logits, probs, values, ph, s);
+  return forward_impl<NipsNet>(ctx, params, states, batch, logits, probs, values, ph, s);
+}
+
+int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                          float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
+                          uint32_t env_offset, int32_t* actions, hipStream_t s) {
+  PhiloxArgs ph;
+  ph.enabled = 1;
+  ph.seed = seed;
+  ph.step_base = step_base;
+  ph.step_off = step_off;
+  ph.env_offset = env_offset;
+  ph.actions = actions;
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    return forward_impl<NatureNet>(ctx, params, states, batch, nullptr, probs, values, ph, s);
+  return forward_impl<NipsNet>(ctx, params, states, batch, nullptr, probs, values, ph, s);
 }
 
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,

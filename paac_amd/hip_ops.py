@@ -76,6 +76,22 @@ class Context(object):
                                          _ptr(probs, torch.float32, B * A, "probs", True),
                                          _ptr(values, torch.float32, B, "values", True), _stream()), "paac_forward")
 
+    def forward_sample(self, params, states, seed, step_base_dev, step_offset, env_offset, actions, probs=None,
+                       values=None):
+        B = states.shape[0]
+        if tuple(states.shape[1:]) != OBS_SHAPE:
+            raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
+        if not (0 < B <= self.max_batch):
+            raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
+        A = self.num_actions
+        _lib.check(self.lib.paac_forward_sample(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                                _ptr(states, torch.uint8, B * 28224, "states"), B,
+                                                _ptr(probs, torch.float32, B * A, "probs", True),
+                                                _ptr(values, torch.float32, B, "values", True), int(seed),
+                                                _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
+                                                int(env_offset), _ptr(actions, torch.int32, B, "actions"), _stream()),
+                   "paac_forward_sample")
+
     def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None):
         B = states.shape[0]
         if tuple(states.shape[1:]) != OBS_SHAPE:
@@ -103,7 +119,6 @@ class Context(object):
                    "paac_clip_rmsprop")
 
     def debug_activation(self, what, batch):
-        spec = {1: None}
         out = torch.empty(batch * 20 * 20 * 64, dtype=torch.float32, device=self.device)
         n = self.lib.paac_debug_activation(self.handle, int(what), int(batch), ctypes.c_void_p(out.data_ptr()), _stream())
         _lib.check(n, "paac_debug_activation")
@@ -113,11 +128,15 @@ class Context(object):
     def prof_enable(self, on=True):
         _lib.check(self.lib.paac_prof_enable(self.handle, 1 if on else 0), "paac_prof_enable")
 
-    def prof_read(self, reset=True):
-        ms = (ctypes.c_double * _lib.PROF_FAMILIES)()
-        cnt = (ctypes.c_int64 * _lib.PROF_FAMILIES)()
-        _lib.check(self.lib.paac_prof_read(self.handle, ms, cnt, 1 if reset else 0), "paac_prof_read")
-        return {self.lib.paac_prof_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(_lib.PROF_FAMILIES)}
+    def prof_read(self):
+        """-> list of (family name, batch, milliseconds), one per kernel-family launch since the last read."""
+        cap = 8192
+        fam = (ctypes.c_int32 * cap)()
+        bat = (ctypes.c_int32 * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = self.lib.paac_prof_read(self.handle, fam, bat, ms, cap)
+        _lib.check(n, "paac_prof_read")
+        return [(self.lib.paac_prof_name(fam[i]).decode(), int(bat[i]), float(ms[i])) for i in range(n)]
 
 
 # -- context-free entry points -------------------------------------------------------------------
@@ -172,6 +191,10 @@ def sample_philox(probs, seed, step_base_dev, step_offset, env_offset, actions):
                                       _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
                                       int(env_offset), _ptr(actions, torch.int32, N, "actions"), _stream()),
                "paac_sample_philox")
+
+
+def debug_clock(out2_dev):
+    _lib.check(_lib.load().paac_debug_clock(_ptr(out2_dev, torch.int64, 2, "out2"), _stream()), "paac_debug_clock")
 
 
 def counter_add(counter_dev, inc):

@@ -71,11 +71,12 @@ class DeviceRollout(object):
         params = L.network.params
         self.states[0].copy_(self.states[T])                      # carry the last observation over
         for t in range(T):
-            L.ctx.forward(params, self.states[t], probs=self.probs, values=self.values[t])
             if self.sampler == "numpy":
+                L.ctx.forward(params, self.states[t], probs=self.probs, values=self.values[t])
                 hip_ops.sample_mt(self.probs, self.mt_state, self.mt_scratch, self.actions[t])
-            else:
-                hip_ops.sample_philox(self.probs, self.sampler_seed, self.tick, t, self.env_offset, self.actions[t])
+            else:       # counter-based sampler fused into the heads kernel
+                L.ctx.forward_sample(params, self.states[t], self.sampler_seed, self.tick, t, self.env_offset,
+                                     self.actions[t], probs=self.probs, values=self.values[t])
             hip_ops.synth_step(self.env_spec["seed"], self.env_offset, self.actions[t],
                                self.env_spec["terminal_threshold"], self.tick, t, self.states[t], self.states[t + 1],
                                self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,

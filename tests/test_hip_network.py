@@ -80,7 +80,17 @@ def test_backward_parity(arch, A, B):
     ctx.loss_backward(p, s, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(adv).cuda(),
                       0.02, grad, loss)
     torch.cuda.synchronize()
-    L, g_ref = onet.loss_and_grads(params, states, np.eye(A)[idx], y, adv, 0.02, arch, dtype=np.float64)
+    # ReLU masks are taken from the device activations: a pre-activation within rounding of 0 may legitimately
+    # land on either side under a different summation order; the forward test bounds the activations themselves.
+    nconv = 3 if arch == "NATURE" else 2
+    masks = {"a%d" % (i + 1): ctx.debug_activation(i + 1, B).cpu().numpy() > 0 for i in range(nconv)}
+    masks["h"] = ctx.debug_activation(4, B).cpu().numpy() > 0
+    ref_fw = onet.forward(params, states, arch, dtype=np.float64, keep=True)["cache"]
+    flips = sum(int((masks[k].reshape(-1) != (ref_fw[k].reshape(-1) > 0)).sum()) for k in masks)
+    total = sum(m.size for m in masks.values())
+    assert flips <= max(4, total * 2e-6), "%d of %d ReLU masks differ from the float64 oracle" % (flips, total)
+    L, g_ref = onet.loss_and_grads(params, states, np.eye(A)[idx], y, adv, 0.02, arch, dtype=np.float64,
+                                   relu_masks=masks)
     lo = loss.cpu().numpy()
     assert abs(lo[0] - L["loss"]) < 1e-4 * max(1.0, abs(L["loss"]))
     assert abs(lo[1] - L["actor"]) < 1e-4 and abs(lo[2] - L["critic"]) < 1e-4
