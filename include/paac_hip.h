@@ -80,14 +80,20 @@ int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* state
                         float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
                         uint32_t env_offset, int32_t* actions, paac_stream_t stream);
 
+/* Training forward alone (into the ctx's TRAINING activation set, separate from the one paac_forward* use, so
+ * a bootstrap inference may run concurrently on another stream).  Follow with paac_loss_backward(forward_done=1). */
+int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream);
+
 /* Loss + gradients of policy_v_network.py:29-57 through the whole network (what
  * optimizer.compute_gradients(loss), actor_learner.py:44, evaluates): runs the training forward
- * on `states`, then backward.  actions = sampled action index per row (the one-hot's argmax,
+ * on `states` (unless forward_done != 0: paac_train_forward already ran on the same batch), then backward; the
+ * weight-gradient kernels run on an internal side stream concurrently with the data-gradient chain (fork/join
+ * by events, so the call is still capturable and ordered on `stream`).  actions = sampled action index per row (the one-hot's argmax,
  * paac.py:27), y = critic target, adv = advantage, batch rows t-major (paac.py:151-154).
  * grad: flat, padded layout.  loss_out (nullable, device float[4]) = {loss, actor, critic, mean entropy}. */
 int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
                        const float* y, const float* adv, int batch, float entropy_beta,
-                       float* grad, float* loss_out, paac_stream_t stream);
+                       float* grad, float* loss_out, int forward_done, paac_stream_t stream);
 
 /* tf.clip_by_global_norm + RMSPropOptimizer.apply_gradients (actor_learner.py:31-34,56-59,70):
  *   g <- grad * grad_scale           (grad_scale = 1/world_size after the sum all-reduce)
@@ -108,6 +114,13 @@ int paac_lr_step(int64_t* global_step_dev, int64_t increment, double initial_lr,
  * fp64 scan, fp32 in/out.  rewards/masks/values/y/adv are [T,N] (t-major). */
 int paac_nstep_returns(const float* v_boot, const float* rewards, const float* masks, const float* values,
                        int T, int N, double gamma, float* y, float* adv, paac_stream_t stream);
+
+/* paac_nstep_returns + paac_lr_step (+ an optional counter bump) in ONE launch: the end-of-rollout bookkeeping of
+ * paac.py:127,140-156.  tick_dev may be NULL. */
+int paac_nstep_returns_tick(const float* v_boot, const float* rewards, const float* masks, const float* values,
+                            int T, int N, double gamma, float* y, float* adv, int64_t* global_step_dev,
+                            int64_t increment, double initial_lr, int64_t lr_annealing_steps, float* lr_out_dev,
+                            uint64_t* tick_dev, uint64_t tick_inc, paac_stream_t stream);
 
 /* paac.py:34-45 bit-exact: probs - float32.epsneg, then numpy legacy multinomial(1, p) per env in
  * index order on ONE MT19937 stream.  mt_state: device uint32[625] = numpy key[624] + pos, advanced
@@ -159,7 +172,8 @@ int paac_graph_launch(paac_graph* g, paac_stream_t stream);
 int paac_graph_destroy(paac_graph* g);
 
 /* Test/debug: copy an internal activation to a caller device buffer (async on stream).
- * what: 1..3 = conv outputs a1..a3 [batch,OH,OW,C], 4 = fc activations h [batch,H]. Returns element count. */
+ * what: 1..3 = conv outputs a1..a3 [batch,OH,OW,C], 4 = fc activations h [batch,H] of the activation set used
+ * last (acting or training); 11..13 / 14 = the gradients wrt them.  Returns the element count. */
 int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream);
 
 /* Diagnostic: writes {s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks} to out2_dev[0..1]. */

@@ -44,13 +44,17 @@ _SIGNATURES = {
     "paac_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "paac_forward_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_void_p, c_uint64,
                                     c_uint32, c_void_p, c_void_p]),
+    "paac_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "paac_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
-                                   c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_void_p]),
     "paac_clip_rmsprop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float,
                                   c_float, c_float, c_float, c_int, c_float, c_void_p, c_void_p]),
     "paac_lr_step": (c_int, [c_void_p, c_int64, c_double, c_int64, c_void_p, c_void_p]),
     "paac_nstep_returns": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p,
                                    c_void_p, c_void_p]),
+    "paac_nstep_returns_tick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p,
+                                        c_void_p, c_void_p, c_int64, c_double, c_int64, c_void_p, c_void_p, c_uint64,
+                                        c_void_p]),
     "paac_sample_mt_scratch_bytes": (c_int64, [c_int, c_int]),
     "paac_sample_mt": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "paac_sample_philox": (c_int, [c_void_p, c_int, c_int, c_uint64, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p]),

@@ -1,5 +1,6 @@
 // C-ABI: context, parameter layout, forward/backward entry points, hipGraph helpers, timing hooks.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <new>
 
@@ -123,20 +124,32 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   c->max_batch = cfg->max_batch;
   const int64_t B = cfg->max_batch;
   const int A = cfg->num_actions;
+  c->fc_splits_max = fc_splits_max();
+  for (int w = 0; w < 2; ++w) {
+    Workspace& W = c->ws[w];
+    for (int i = 0; i < c->spec.nconv; ++i) {
+      const ConvSpec& cs = c->spec.conv[i];
+      PAAC_CHECK_HIP(hipMalloc(&W.act[i], (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float)));
+    }
+    PAAC_CHECK_HIP(hipMalloc(&W.fc_slab, (size_t)c->fc_splits_max * B * c->spec.fc * sizeof(float)));
+    PAAC_CHECK_HIP(hipMalloc(&W.h, (size_t)B * c->spec.fc * sizeof(float)));
+    PAAC_CHECK_HIP(hipMalloc(&W.probs, (size_t)B * A * sizeof(float)));
+    PAAC_CHECK_HIP(hipMalloc(&W.logits, (size_t)B * A * sizeof(float)));
+    PAAC_CHECK_HIP(hipMalloc(&W.values, (size_t)B * sizeof(float)));
+  }
   for (int i = 0; i < c->spec.nconv; ++i) {
     const ConvSpec& cs = c->spec.conv[i];
-    const size_t bytes = (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float);
-    PAAC_CHECK_HIP(hipMalloc(&c->act[i], bytes));
-    PAAC_CHECK_HIP(hipMalloc(&c->dact[i], bytes));
+    PAAC_CHECK_HIP(hipMalloc(&c->dact[i], (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float)));
   }
-  c->fc_splits_max = fc_splits_max();
-  PAAC_CHECK_HIP(hipMalloc(&c->fc_slab, (size_t)c->fc_splits_max * B * c->spec.fc * sizeof(float)));
-  PAAC_CHECK_HIP(hipMalloc(&c->h, (size_t)B * c->spec.fc * sizeof(float)));
   PAAC_CHECK_HIP(hipMalloc(&c->dh, (size_t)B * c->spec.fc * sizeof(float)));
-  PAAC_CHECK_HIP(hipMalloc(&c->dhead, (size_t)B * (A + 1) * sizeof(float)));
-  PAAC_CHECK_HIP(hipMalloc(&c->probs, (size_t)B * A * sizeof(float)));
-  PAAC_CHECK_HIP(hipMalloc(&c->logits, (size_t)B * A * sizeof(float)));
-  PAAC_CHECK_HIP(hipMalloc(&c->values, (size_t)B * sizeof(float)));
+  // PAAC_FORK_WGRAD=1: run the weight-gradient kernels on a side stream (fork/join by events) concurrently with
+  // the data-gradient chain.  Off by default: on ROCm 7.2 each fork/join inside a replayed hipGraph costs
+  // 10-16 us, more than the overlap returns at the training batch of 160 (profiles/).
+  const char* fk = getenv("PAAC_FORK_WGRAD");
+  c->side = nullptr;
+  if (fk && fk[0] == '1') PAAC_CHECK_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (int i = 0; i < 4; ++i) PAAC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming));
+  PAAC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   c->wslab_floats = wslab_floats_needed(cfg->arch);
   PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
   PAAC_CHECK_HIP(hipMalloc(&c->partials, 4096 * sizeof(float)));
@@ -157,13 +170,23 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
 
 int paac_destroy(paac_ctx* c) {
   if (!c) return 0;
-  for (int i = 0; i < 3; ++i) {
-    if (c->act[i]) (void)hipFree(c->act[i]);
-    if (c->dact[i]) (void)hipFree(c->dact[i]);
+  for (int w = 0; w < 2; ++w) {
+    Workspace& W = c->ws[w];
+    for (int i = 0; i < 3; ++i)
+      if (W.act[i]) (void)hipFree(W.act[i]);
+    float* bufs[] = {W.fc_slab, W.h, W.probs, W.logits, W.values};
+    for (float* b : bufs)
+      if (b) (void)hipFree(b);
   }
-  float* bufs[] = {c->fc_slab, c->h, c->dh, c->dhead, c->probs, c->logits, c->values, c->wslab, c->partials};
+  for (int i = 0; i < 3; ++i)
+    if (c->dact[i]) (void)hipFree(c->dact[i]);
+  float* bufs[] = {c->dh, c->wslab, c->partials};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  for (int i = 0; i < 4; ++i)
+    if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
     if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
     if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -181,7 +204,17 @@ int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int 
   PAAC_REQUIRE(ctx && params && states, "paac_forward: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_forward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
-  const int rc = launch_forward(ctx, params, states, batch, true, logits, probs, values, (hipStream_t)stream);
+  const int rc = launch_forward(ctx, 0, params, states, batch, logits, probs, values, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states, "paac_train_forward: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_train_forward: batch %d outside (0, max_batch=%d]", batch,
+               ctx->max_batch);
+  const int rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -202,12 +235,16 @@ int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* state
 
 int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                        const float* adv, int batch, float entropy_beta, float* grad, float* loss_out,
-                       paac_stream_t stream) {
+                       int forward_done, paac_stream_t stream) {
   PAAC_REQUIRE(ctx && params && states && actions && y && adv && grad, "paac_loss_backward: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_loss_backward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
-  int rc = launch_forward(ctx, params, states, batch, false, nullptr, nullptr, nullptr, (hipStream_t)stream);
-  if (rc) return rc;
+  int rc = 0;
+  if (!forward_done) {
+    rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  ctx->last_ws = 1;
   rc = launch_backward(ctx, params, states, actions, y, adv, batch, entropy_beta, grad, loss_out, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
@@ -218,12 +255,13 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
   PAAC_REQUIRE(ctx && out && batch > 0 && batch <= ctx->max_batch, "paac_debug_activation: bad arguments");
   const float* src = nullptr;
   int64_t n = 0;
+  const Workspace& W = ctx->ws[ctx->last_ws];
   if (what >= 1 && what <= ctx->spec.nconv) {
     const ConvSpec& cs = ctx->spec.conv[what - 1];
-    src = ctx->act[what - 1];
+    src = W.act[what - 1];
     n = (int64_t)batch * cs.oh * cs.ow * cs.cout;
   } else if (what == 4) {
-    src = ctx->h;
+    src = W.h;
     n = (int64_t)batch * ctx->spec.fc;
   } else if (what >= 11 && what <= 10 + ctx->spec.nconv) {
     const ConvSpec& cs = ctx->spec.conv[what - 11];

@@ -53,26 +53,37 @@ static_assert(F_MISC + 1 == PAAC_PROF_FAMILIES, "family count");
 
 }  // namespace paac
 
+namespace paac {
+// Forward activations of one batch.  Two sets per ctx: [0] acting / bootstrap (paac_forward*), [1] training
+// (paac_train_forward + paac_loss_backward) -- so the bootstrap inference of a cycle can run concurrently with
+// the training forward on another stream without clobbering the activations the backward pass needs.
+struct Workspace {
+  float* act[3];   // conv outputs a1..a3 (fp32 NHWC)
+  float* fc_slab;  // [FC_SPLITS_MAX][max_batch][H] split-K partials of the fc layer
+  float* h;        // [max_batch][H] fc activations
+  float* probs;    // [max_batch][A]
+  float* values;   // [max_batch]
+  float* logits;   // [max_batch][A]
+};
+}  // namespace paac
+
 struct paac_ctx {
   paac_cfg cfg;
   paac::ArchSpec spec;
   paac_layout layout;
   int max_batch;
-  // activations (fp32, NHWC), sized for max_batch
-  float* act[3];   // conv outputs a1..a3
+  paac::Workspace ws[2];
+  int last_ws;
   float* dact[3];  // gradients wrt conv outputs (post ReLU mask)
-  float* fc_slab;  // [FC_SPLITS_MAX][max_batch][H] split-K partials of the fc layer
-  float* h;        // [max_batch][H] fc activations
   float* dh;       // [max_batch][H]
-  float* dhead;    // [max_batch][A+1] dlogits | dv
-  float* probs;    // [max_batch][A]  (kept for backward)
-  float* values;   // [max_batch]
-  float* logits;   // [max_batch][A]
-  float* wslab;    // wgrad split-K slabs (all layers, see slab_off)
+  float* wslab;    // wgrad split-K slabs (all layers)
   int64_t wslab_floats;
-  float* partials; // sum-of-squares partials [1024] + loss partials
-  void* seg_table; // device table for grad finalize
+  float* partials; // sum-of-squares partials
   int fc_splits_max;
+  // side stream + events: wgrad kernels run concurrently with the dgrad chain (fork/join, capturable)
+  hipStream_t side;
+  hipEvent_t ev_fork[4];
+  hipEvent_t ev_join;
   // profiling hooks
   int prof_on;
   static constexpr int PROF_MAX_EVENTS = 8192;
@@ -104,8 +115,8 @@ struct ProfScope {
 };
 
 // launchers implemented in the kernel translation units
-int launch_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, bool want_outputs,
-                   float* logits, float* probs, float* values, hipStream_t s);
+int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,
+                   float* probs, float* values, hipStream_t s);
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
                           float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
                           uint32_t env_offset, int32_t* actions, hipStream_t s);

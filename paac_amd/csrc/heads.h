@@ -1,0 +1,364 @@
+// Actor / critic heads of the PAAC network on gfx950 (policy_v_network.py:24-57): forward (fc split-K slab
+// reduction + bias + ReLU, two tiny GEMVs, softmax, optional counter-based categorical sampling) and the loss
+// gradient wrt the heads.  HBM/latency-bound kernels: every independent global load is issued before anything
+// is consumed, per-thread arrays are sized by a compile-time action-count bucket AP (4 / 8 / 20 / 32) so they stay
+// in registers, and block-wide sums go through LDS in two short stages instead of long ds_bpermute chains.
+#pragma once
+#include "common.h"
+
+namespace paac {
+
+constexpr int FC_SPLITS_MAX = 4;   // fc forward split-K slabs (summed here)
+constexpr int MAXA = 32;
+
+#ifdef PAAC_DMM_STAMPS
+__device__ unsigned long long* g_stamps_dev = nullptr;
+#define HEADS_STAMP_INIT() unsigned long long* stamp_ptr = g_stamps_dev
+#define HEADS_STAMP(i)                                                                                         \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (stamp_ptr && threadIdx.x == 0) stamp_ptr[(long)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#else
+#define HEADS_STAMP_INIT()
+#define HEADS_STAMP(i)
+#endif
+
+// Block-wide sums (256 threads) of NV per-thread values: out_lds[a] = sum over threads of vals[a].
+// scratch: NV*256 + NV*8 floats of LDS.  Ends with a barrier.
+template <int NV>
+__device__ __forceinline__ void block_sums_256(const float (&vals)[NV], float* scratch, float* out_lds) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int a = 0; a < NV; ++a) scratch[a * 256 + tid] = vals[a];
+  __syncthreads();
+  float* stage = scratch + NV * 256;
+  for (int u = tid; u < NV * 8; u += 256) {
+    const int a = u >> 3, c = u & 7;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = scratch[a * 256 + c * 32 + ((i + c) & 31)];   // rotated start: spread the banks
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += v[i];
+    stage[u] = t;
+  }
+  __syncthreads();
+  if (tid < NV) {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) t += stage[tid * 8 + c];
+    out_lds[tid] = t;
+  }
+  __syncthreads();
+}
+
+struct PhiloxArgs {
+  int enabled;
+  uint64_t seed;
+  const uint64_t* step_base;
+  uint64_t step_off;
+  uint32_t env_offset;
+  int32_t* actions;
+};
+
+__device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+// One 256-thread workgroup per batch row.
+template <int H, int AP>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ slab, int splits, long slab_stride,
+                                                        const float* __restrict__ fc_b, const float* __restrict__ Wa,
+                                                        const float* __restrict__ ba, const float* __restrict__ Wc,
+                                                        const float* __restrict__ bc, int A, float* __restrict__ h_out,
+                                                        float* __restrict__ logits_ws, float* __restrict__ probs_ws,
+                                                        float* __restrict__ values_ws, float* __restrict__ logits_out,
+                                                        float* __restrict__ probs_out, float* __restrict__ values_out,
+                                                        const PhiloxArgs ph) {
+  constexpr int JPT = H / 256;
+  constexpr int NV = AP + 1;                 // A logits (padded) + value
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x;
+  HEADS_STAMP_INIT();
+  HEADS_STAMP(0);
+  // ---- every independent load first ---------------------------------------------------------------
+  const float head_bias = (tid < A) ? ba[tid] : ((tid == AP) ? bc[0] : 0.f);
+  const uint64_t step0 = (ph.enabled && ph.step_base && tid == 0) ? *ph.step_base : 0ull;
+  float sv[JPT][FC_SPLITS_MAX], bj[JPT], wcj[JPT], waj[JPT][AP];
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int j = tid + jj * 256;
+#pragma unroll
+    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) sv[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)i * H + j];
+    bj[jj] = fc_b[j];
+    wcj[jj] = Wc[j];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) waj[jj][a] = Wa[j * A + (a < A ? a : 0)];
+  }
+  float part[NV];
+#pragma unroll
+  for (int a = 0; a < NV; ++a) part[a] = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int j = tid + jj * 256;
+    float s = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) s += (sp < splits) ? sv[jj][sp] : 0.f;
+    s = fmaxf(s + bj[jj], 0.f);
+    h_out[(long)i * H + j] = s;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) part[a] += (a < A) ? s * waj[jj][a] : 0.f;
+    part[AP] += s * wcj[jj];
+  }
+  HEADS_STAMP(1);
+  __shared__ float scratch[NV * 256 + NV * 8];
+  __shared__ float lg[NV];
+  block_sums_256<NV>(part, scratch, lg);
+  HEADS_STAMP(2);
+  if (tid < NV) lg[tid] += head_bias;
+  __syncthreads();
+  HEADS_STAMP(3);
+  if (tid == 0) {
+    float m = lg[0];
+#pragma unroll
+    for (int a = 1; a < AP; ++a) m = (a < A) ? fmaxf(m, lg[a]) : m;
+    float e[AP];
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      e[a] = (a < A) ? expf(lg[a] - m) : 0.f;
+      sum += e[a];
+    }
+    float u = 0.f;
+    if (ph.enabled) {
+      const uint64_t step = step0 + ph.step_off;
+      const uint32_t w = philox_word0(ph.env_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32), 0u,
+                                      (uint32_t)ph.seed, (uint32_t)(ph.seed >> 32));
+      u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    }
+    int act = A - 1;
+    bool found = false;
+    float cum = 0.f;
+#pragma unroll
+    for (int a = 0; a < AP; ++a)
+      if (a < A) {
+        const float pa = e[a] / sum;
+        probs_ws[(long)i * A + a] = pa;
+        logits_ws[(long)i * A + a] = lg[a];
+        if (probs_out) probs_out[(long)i * A + a] = pa;
+        if (logits_out) logits_out[(long)i * A + a] = lg[a];
+        if (a < A - 1) {
+          cum += pa;
+          if (!found && u < cum) {
+            act = a;
+            found = true;
+          }
+        }
+      }
+    values_ws[i] = lg[AP];
+    if (values_out) values_out[i] = lg[AP];
+    if (ph.enabled) ph.actions[i] = act;
+  }
+  HEADS_STAMP(4);
+}
+
+// Loss gradient wrt the heads of one row (policy_v_network.py:29-57; analytic form: DESIGN.md / SURVEY A.4):
+//   s = 5/B; dv = s*0.5*(v - y); g_a = -(adv*1[a=act]/(pi_a+eps) - beta*(log(pi_a+eps) + pi_a/(pi_a+eps)))
+//   dlogit_a = s*pi_a*(g_a - sum_j g_j pi_j)
+// out[0..AP) = dlogits (0 beyond A), out[AP] = dv.  stats (optional): actor term, critic term, entropy.
+template <int AP>
+__device__ __forceinline__ void head_grad_row(const float (&pi)[AP], float v, int act, float y, float adv, float beta,
+                                              float s, int A, float (&out)[AP + 1], float* stats) {
+  const float eps = 1e-30f;
+  float g[AP];
+  float dot = 0.f, ent = 0.f, logp = 0.f;
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    const bool on = a < A;
+    const float p = on ? pi[a] : 1.f;
+    const float lp = logf(p + eps);
+    const float inv = 1.0f / (p + eps);
+    const float oh = (a == act) ? 1.f : 0.f;
+    g[a] = on ? -(adv * oh * inv - beta * (lp + p * inv)) : 0.f;
+    dot += on ? g[a] * p : 0.f;
+    ent -= on ? p * lp : 0.f;
+    logp += on ? oh * lp : 0.f;
+  }
+#pragma unroll
+  for (int a = 0; a < AP; ++a) out[a] = (a < A) ? s * pi[a] * (g[a] - dot) : 0.f;
+  out[AP] = s * 0.5f * (v - y);
+  if (stats) {
+    stats[0] = -(logp * adv + beta * ent);   // actor objective term
+    stats[1] = 0.25f * (y - v) * (y - v);    // critic term
+    stats[2] = ent;
+  }
+}
+
+template <int AP>
+__device__ __forceinline__ void load_row_and_grad(const float* __restrict__ probs, const float* __restrict__ values,
+                                                  const int32_t* __restrict__ actions, const float* __restrict__ y,
+                                                  const float* __restrict__ adv, int i, int A, float beta, float s,
+                                                  float (&out)[AP + 1], float* stats) {
+  float pi[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) pi[a] = probs[(long)i * A + (a < A ? a : 0)];
+  head_grad_row<AP>(pi, values[i], actions[i], y[i], adv[i], beta, s, A, out, stats);
+}
+
+// One launch, three roles by blockIdx:
+//   [0, B)          row i -> dH[i,:] = (dlogits Wa^T + dv Wc^T) * 1[h > 0]
+//   [B, B + H/32)   head weight gradients for 32 columns j: 8 row-groups x 32 columns per workgroup, dlogits
+//                   recomputed into LDS in chunks of 256 rows, h rows loaded in batches
+//   B + H/32        head bias gradients + loss scalars
+constexpr int HB_CHUNK = 256;
+template <int H, int AP>
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ values,
+                                                        const int32_t* __restrict__ actions, const float* __restrict__ y,
+                                                        const float* __restrict__ adv, const float* __restrict__ h,
+                                                        const float* __restrict__ Wa, const float* __restrict__ Wc,
+                                                        int A, int B, float beta, float* __restrict__ dH,
+                                                        float* __restrict__ gWa, float* __restrict__ gba,
+                                                        float* __restrict__ gWc, float* __restrict__ gbc,
+                                                        float* __restrict__ loss_out) {
+  constexpr int NV = AP + 1;
+  constexpr int NS = NV + 3;                       // + 3 loss statistics (role 3)
+  const int tid = threadIdx.x;
+  const float s = 5.0f / (float)B;
+  HEADS_STAMP_INIT();
+  HEADS_STAMP(0);
+  __shared__ float smem[NS * 256 + NS * 8 > HB_CHUNK * NV ? NS * 256 + NS * 8 : HB_CHUNK * NV];
+  __shared__ float red[NS];
+  if ((int)blockIdx.x < B) {
+    // ---- role 1 ----
+    const int i = blockIdx.x;
+    constexpr int JPT = H / 256;
+    float hv[JPT], wcj[JPT], waj[JPT][AP];
+#pragma unroll
+    for (int jj = 0; jj < JPT; ++jj) {
+      const int j = tid + jj * 256;
+      hv[jj] = h[(long)i * H + j];
+      wcj[jj] = Wc[j];
+#pragma unroll
+      for (int a = 0; a < AP; ++a) waj[jj][a] = Wa[j * A + (a < A ? a : 0)];
+    }
+    float dl[NV];
+    load_row_and_grad<AP>(probs, values, actions, y, adv, i, A, beta, s, dl, nullptr);   // every thread: same row
+#pragma unroll
+    for (int jj = 0; jj < JPT; ++jj) {
+      const int j = tid + jj * 256;
+      float acc = dl[AP] * wcj[jj];
+#pragma unroll
+      for (int a = 0; a < AP; ++a) acc += dl[a] * waj[jj][a];
+      dH[(long)i * H + j] = hv[jj] > 0.f ? acc : 0.f;
+    }
+    HEADS_STAMP(1);
+    return;
+  }
+  const int role = blockIdx.x - B;
+  if (role < H / 32) {
+    // ---- role 2 ----
+    const int jj = tid & 31, ig = tid >> 5;
+    const int j = role * 32 + jj;
+    float acc[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) acc[a] = 0.f;
+    for (int i0 = 0; i0 < B; i0 += HB_CHUNK) {
+      const int cnt = min(HB_CHUNK, B - i0);
+      float hv[HB_CHUNK / 8];
+#pragma unroll
+      for (int q = 0; q < HB_CHUNK / 8; ++q) {       // issue the whole batch of h loads first
+        const int r = ig + 8 * q;
+        hv[q] = h[(long)(i0 + (r < cnt ? r : 0)) * H + j];
+      }
+      __syncthreads();
+      if (tid < cnt) {
+        float dl[NV];
+        load_row_and_grad<AP>(probs, values, actions, y, adv, i0 + tid, A, beta, s, dl, nullptr);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) smem[tid * NV + a] = dl[a];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < HB_CHUNK / 8; ++q) {
+        const int r = ig + 8 * q;
+        if (r < cnt) {
+#pragma unroll
+          for (int a = 0; a < NV; ++a) acc[a] += hv[q] * smem[r * NV + a];
+        }
+      }
+    }
+    HEADS_STAMP(2);
+    __syncthreads();
+    // reduce the 8 row-groups through LDS: smem as [8][32][NV]
+#pragma unroll
+    for (int a = 0; a < NV; ++a) smem[(ig * 32 + jj) * NV + a] = acc[a];
+    __syncthreads();
+    for (int u = tid; u < 32 * NV; u += 256) {
+      const int c = u / NV, a = u - c * NV;
+      float v = 0.f;
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) v += smem[(g8 * 32 + c) * NV + a];
+      const int jo = role * 32 + c;
+      if (a == AP) gWc[jo] = v;
+      else if (a < A) gWa[jo * A + a] = v;
+    }
+    HEADS_STAMP(3);
+    return;
+  }
+  // ---- role 3: bias gradients + loss scalars ----
+  float accv[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) accv[a] = 0.f;
+  for (int i = tid; i < B; i += 256) {
+    float dl[NV], stats[3];
+    load_row_and_grad<AP>(probs, values, actions, y, adv, i, A, beta, s, dl, stats);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) accv[a] += dl[a];
+    accv[NV] += stats[0]; accv[NV + 1] += stats[1]; accv[NV + 2] += stats[2];
+  }
+  block_sums_256<NS>(accv, smem, red);
+  if (tid < A) gba[tid] = red[tid];
+  if (tid == AP) gbc[0] = red[AP];
+  if (tid == 0 && loss_out) {
+    const float actor = red[NV] / (float)B;
+    const float critic = red[NV + 1] / (float)B;
+    loss_out[0] = 5.0f * (actor + critic);
+    loss_out[1] = actor;
+    loss_out[2] = critic;
+    loss_out[3] = red[NV + 2] / (float)B;
+  }
+  HEADS_STAMP(4);
+}
+
+// Dispatch on the action-count bucket.
+template <int H, class... Args>
+inline void launch_heads_fwd(int A, dim3 grid, hipStream_t s, Args... args) {
+  if (A <= 4) hipLaunchKernelGGL((heads_fwd_kernel<H, 4>), grid, dim3(256), 0, s, args...);
+  else if (A <= 8) hipLaunchKernelGGL((heads_fwd_kernel<H, 8>), grid, dim3(256), 0, s, args...);
+  else if (A <= 20) hipLaunchKernelGGL((heads_fwd_kernel<H, 20>), grid, dim3(256), 0, s, args...);
+  else hipLaunchKernelGGL((heads_fwd_kernel<H, 32>), grid, dim3(256), 0, s, args...);
+}
+template <int H, class... Args>
+inline void launch_heads_bwd(int A, dim3 grid, hipStream_t s, Args... args) {
+  if (A <= 4) hipLaunchKernelGGL((heads_bwd_kernel<H, 4>), grid, dim3(256), 0, s, args...);
+  else if (A <= 8) hipLaunchKernelGGL((heads_bwd_kernel<H, 8>), grid, dim3(256), 0, s, args...);
+  else if (A <= 20) hipLaunchKernelGGL((heads_bwd_kernel<H, 20>), grid, dim3(256), 0, s, args...);
+  else hipLaunchKernelGGL((heads_bwd_kernel<H, 32>), grid, dim3(256), 0, s, args...);
+}
+
+}  // namespace paac

@@ -6,10 +6,30 @@ namespace paac {
 
 // =============================================================================================
 // n-step returns (paac.py:140-149), fp64 scan like the reference's numpy buffers.
+struct CycleTick {          // optional bookkeeping folded into the returns kernel (one launch instead of three)
+  int64_t* global_step;     // += step_inc, then lr = f32(lr0 - step*lr0/anneal)   (actor_learner.py:119-123)
+  int64_t step_inc;
+  double lr0;
+  int64_t anneal;
+  float* lr_out;
+  uint64_t* tick;           // += tick_inc (sampler / synthetic-env frame counter)
+  uint64_t tick_inc;
+};
+
 __global__ void nstep_returns_kernel(const float* __restrict__ v_boot, const float* __restrict__ rewards,
                                      const float* __restrict__ masks, const float* __restrict__ values, int T, int N,
-                                     double gamma, float* __restrict__ y, float* __restrict__ adv) {
+                                     double gamma, float* __restrict__ y, float* __restrict__ adv, const CycleTick ct) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) {
+    if (ct.global_step) {
+      const int64_t step = *ct.global_step + ct.step_inc;
+      *ct.global_step = step;
+      double lr = 0.0;
+      if (step <= ct.anneal) lr = ct.lr0 - ((double)step * ct.lr0 / (double)ct.anneal);
+      *ct.lr_out = (float)lr;
+    }
+    if (ct.tick) *ct.tick += ct.tick_inc;
+  }
   if (e >= N) return;
   // paac.py:146-147 as numpy evaluates it: estimated_return starts as the FLOAT32 network output, so the first
   // `gamma * estimated_return` is a float32 product (python float x float32 array -> float32, in numpy 1.x
@@ -461,8 +481,25 @@ extern "C" {
 int paac_nstep_returns(const float* v_boot, const float* rewards, const float* masks, const float* values, int T, int N,
                        double gamma, float* y, float* adv, paac_stream_t stream) {
   PAAC_REQUIRE(T > 0 && N > 0, "paac_nstep_returns: T=%d N=%d", T, N);
+  CycleTick ct;
+  memset(&ct, 0, sizeof(ct));
   hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, v_boot, rewards, masks,
-                     values, T, N, gamma, y, adv);
+                     values, T, N, gamma, y, adv, ct);
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_nstep_returns_tick(const float* v_boot, const float* rewards, const float* masks, const float* values, int T,
+                            int N, double gamma, float* y, float* adv, int64_t* global_step_dev, int64_t increment,
+                            double initial_lr, int64_t lr_annealing_steps, float* lr_out_dev, uint64_t* tick_dev,
+                            uint64_t tick_inc, paac_stream_t stream) {
+  PAAC_REQUIRE(T > 0 && N > 0, "paac_nstep_returns_tick: T=%d N=%d", T, N);
+  PAAC_REQUIRE(global_step_dev && lr_out_dev && lr_annealing_steps > 0, "paac_nstep_returns_tick: bad arguments");
+  CycleTick ct;
+  ct.global_step = global_step_dev; ct.step_inc = increment; ct.lr0 = initial_lr; ct.anneal = lr_annealing_steps;
+  ct.lr_out = lr_out_dev; ct.tick = tick_dev; ct.tick_inc = tick_inc;
+  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, v_boot, rewards, masks,
+                     values, T, N, gamma, y, adv, ct);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

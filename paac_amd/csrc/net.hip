@@ -4,6 +4,7 @@
 // Layout contract: activations NHWC fp32, conv weights HWIO, fc weights [in,out], flatten in HWC order
 // (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
 #include "dmm.h"
+#include "heads.h"
 
 namespace paac {
 
@@ -30,13 +31,12 @@ struct NipsNet {
   using G2D = Geom<9, 9, 32, 10, 10, 1, 1, 1, 2, 2>;
 };
 
-constexpr int FC_SPLITS_MAX = 16;
 constexpr int W_SPLITS_MAX = 64;
-constexpr int MAXA = 32;
 
 #ifdef PAAC_DMM_STAMPS
 unsigned long long* g_stamps = nullptr;   // diagnostic build: the `which`-th dmm launch after the call is stamped
 int g_stamp_which = -1, g_stamp_calls = 0;
+extern "C" void paac_debug_set_heads_stamps(unsigned long long* p);
 extern "C" void paac_debug_set_stamps(unsigned long long* p, int which) {
   g_stamps = p;
   g_stamp_which = which;
@@ -77,11 +77,11 @@ static void launch_fwd(const GemmArgs& g, int ksplit, hipStream_t s) {
   if (rows16 * ncol * ksplit <= 256) {
     launch_dmm<G, U8, FRAG_K, FRAG_MN, 1, VN, 1, 1, 8, 1, EPI, false, 5>(g, ksplit, ksplit, s);   // 16 rows, K over 8 waves
   } else if (rows16 * ncol * ksplit <= 1024) {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 1, 1, 4, 1, EPI, false, 4>(g, ksplit, ksplit, s);   // 32 rows, K over 4 waves
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 1, 1, 4, 1, EPI, false, 3>(g, ksplit, ksplit, s);   // 32 rows, K over 4 waves
   } else if (rows16 * ncol * ksplit <= 4096) {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 2, 1, 2, 1, EPI, false, 4>(g, ksplit, ksplit, s);   // 64 rows, K over 2 waves
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 2, 1, 2, 1, EPI, false, 2>(g, ksplit, ksplit, s);   // 64 rows, K over 2 waves
   } else {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 4, 1, 1, 1, EPI, false, 4>(g, ksplit, ksplit, s);   // 128 rows, no K split
+    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 4, 1, 1, 1, EPI, false, 2>(g, ksplit, ksplit, s);   // 128 rows, no K split
   }
 }
 
@@ -93,9 +93,9 @@ static void launch_dgrad(const GemmArgs& g, int zdim, hipStream_t s) {
   if (tiles <= 384) {
     launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 1, 1, 4, BCO, EPI, false, 4>(g, zdim, 1, s);
   } else if (tiles <= 1536) {
-    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 2, 1, 2, BCO, EPI, false, 4>(g, zdim, 1, s);
+    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 2, 1, 2, BCO, EPI, false, 3>(g, zdim, 1, s);
   } else {
-    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 4, 1, 1, BCO, EPI, false, 4>(g, zdim, 1, s);
+    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 4, 1, 1, BCO, EPI, false, 2>(g, zdim, 1, s);
   }
 }
 
@@ -107,293 +107,12 @@ static int launch_wgrad(GemmArgs g, int max_split, hipStream_t s) {
   const int ngroups = (g.K + 15) / 16;
   if (ngroups >= 32) {
     const int ks = pick_ksplit(tiles, 4, ngroups, max_split);
-    launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 4, 1, EPI_SLAB, true, 3>(g, ks, ks, s);
+    launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 4, 1, EPI_SLAB, true, 2>(g, ks, ks, s);
     return ks;
   }
   const int ks = 1;
-  launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 2, 1, EPI_SLAB, true, 3>(g, ks, ks, s);
+  launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 2, 1, EPI_SLAB, true, 2>(g, ks, ks, s);
   return ks;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Heads forward: h = relu(sum of fc split-K slabs + b); logits = h Wa + ba; pi = softmax; v = h Wc + bc
-// (policy_v_network.py:24-26,37 / networks.py:84-89), optionally followed by the counter-based categorical
-// sampler (wavefront-level: one row per workgroup, shuffles for the A+1 dot products).
-struct PhiloxArgs {
-  int enabled;
-  uint64_t seed;
-  const uint64_t* step_base;
-  uint64_t step_off;
-  uint32_t env_offset;
-  int32_t* actions;
-};
-
-__device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c0;
-}
-
-template <int H>
-__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ slab, int splits, long slab_stride,
-                                                        const float* __restrict__ fc_b, const float* __restrict__ Wa,
-                                                        const float* __restrict__ ba, const float* __restrict__ Wc,
-                                                        const float* __restrict__ bc, int A, float* __restrict__ h_out,
-                                                        float* __restrict__ logits_ws, float* __restrict__ probs_ws,
-                                                        float* __restrict__ values_ws, float* __restrict__ logits_out,
-                                                        float* __restrict__ probs_out, float* __restrict__ values_out,
-                                                        const PhiloxArgs ph) {
-  const int i = blockIdx.x;
-  const int tid = threadIdx.x;
-  float part[MAXA + 1];
-#pragma unroll
-  for (int a = 0; a <= MAXA; ++a) part[a] = 0.f;
-  constexpr int JPT = H / 256;
-#pragma unroll
-  for (int jj = 0; jj < JPT; ++jj) {
-    const int j = tid + jj * 256;
-    float sv[FC_SPLITS_MAX];
-#pragma unroll
-    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) sv[sp] = (sp < splits) ? slab[sp * slab_stride + (long)i * H + j] : 0.f;
-    float s = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) s += sv[sp];
-    s = fmaxf(s + fc_b[j], 0.f);
-    h_out[(long)i * H + j] = s;
-#pragma unroll
-    for (int a = 0; a < MAXA; ++a)
-      if (a < A) part[a] += s * Wa[j * A + a];
-    part[MAXA] += s * Wc[j];
-  }
-  __shared__ float red[4][MAXA + 1];
-  __shared__ float lg[MAXA + 1];
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int a = 0; a <= MAXA; ++a) {
-    if (a < A || a == MAXA) {
-      float v = part[a];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) red[wave][a] = v;
-    }
-  }
-  __syncthreads();
-  if (tid <= MAXA && (tid < A || tid == MAXA)) {
-    const float b = (tid == MAXA) ? bc[0] : ba[tid];
-    lg[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + b;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float m = lg[0];
-    for (int a = 1; a < A; ++a) m = fmaxf(m, lg[a]);
-    float e[MAXA];
-    float sum = 0.f;
-#pragma unroll
-    for (int a = 0; a < MAXA; ++a)
-      if (a < A) {
-        e[a] = expf(lg[a] - m);
-        sum += e[a];
-      }
-    float u = 0.f;
-    if (ph.enabled) {
-      const uint64_t step = (ph.step_base ? *ph.step_base : 0ull) + ph.step_off;
-      const uint32_t w = philox_word0(ph.env_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32), 0u,
-                                      (uint32_t)ph.seed, (uint32_t)(ph.seed >> 32));
-      u = (float)(w >> 8) * (1.0f / 16777216.0f);
-    }
-    int act = A - 1;
-    bool found = false;
-    float cum = 0.f;
-#pragma unroll
-    for (int a = 0; a < MAXA; ++a)
-      if (a < A) {
-        const float pa = e[a] / sum;
-        probs_ws[(long)i * A + a] = pa;
-        logits_ws[(long)i * A + a] = lg[a];
-        if (probs_out) probs_out[(long)i * A + a] = pa;
-        if (logits_out) logits_out[(long)i * A + a] = lg[a];
-        if (a < A - 1) {
-          cum += pa;
-          if (!found && u < cum) {
-            act = a;
-            found = true;
-          }
-        }
-      }
-    values_ws[i] = lg[MAXA];
-    if (values_out) values_out[i] = lg[MAXA];
-    if (ph.enabled) ph.actions[i] = act;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Loss gradient wrt heads (policy_v_network.py:29-57; analytic form in DESIGN.md / SURVEY A.4):
-//   s = 5/B; dv = s*0.5*(v - y); g_a = -(adv*1[a=act]/(pi_a+eps) - beta*(log(pi_a+eps) + pi_a/(pi_a+eps)))
-//   dlogit_a = s*pi_a*(g_a - sum_j g_j pi_j)
-__device__ __forceinline__ void head_grad_row(const float* __restrict__ pi, float v, int act, float y, float adv,
-                                              float beta, float s, int A, float* dl /*[A]*/, float* dv, float* stats) {
-  const float eps = 1e-30f;
-  float g[MAXA];
-  float dot = 0.f, ent = 0.f, logp = 0.f;
-#pragma unroll
-  for (int a = 0; a < MAXA; ++a)
-    if (a < A) {
-      const float p = pi[a];
-      const float lp = logf(p + eps);
-      const float inv = 1.0f / (p + eps);
-      const float oh = (a == act) ? 1.f : 0.f;
-      g[a] = -(adv * oh * inv - beta * (lp + p * inv));
-      dot += g[a] * p;
-      ent -= p * lp;
-      logp += oh * lp;
-    }
-#pragma unroll
-  for (int a = 0; a < MAXA; ++a)
-    if (a < A) dl[a] = s * pi[a] * (g[a] - dot);
-  *dv = s * 0.5f * (v - y);
-  if (stats) {
-    stats[0] = -(logp * adv + beta * ent);      // actor objective term
-    stats[1] = 0.25f * (y - v) * (y - v);       // critic term
-    stats[2] = ent;
-  }
-}
-
-// One launch, three roles by blockIdx:
-//   [0, B)              : row i -> dH[i,:] = (dlogits Wa^T + dv Wc^T) * 1[h > 0]
-//   [B, B + H/32)       : head weight gradients for 32 values of j: 8 row-groups x 32 columns per workgroup,
-//                         dlogits recomputed into LDS in chunks of 256 rows
-//   B + H/32            : head bias gradients + loss scalars
-constexpr int HB_CHUNK = 256;
-template <int H>
-__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ values,
-                                                        const int32_t* __restrict__ actions, const float* __restrict__ y,
-                                                        const float* __restrict__ adv, const float* __restrict__ h,
-                                                        const float* __restrict__ Wa, const float* __restrict__ Wc,
-                                                        int A, int B, float beta, float* __restrict__ dH,
-                                                        float* __restrict__ gWa, float* __restrict__ gba,
-                                                        float* __restrict__ gWc, float* __restrict__ gbc,
-                                                        float* __restrict__ loss_out) {
-  const int tid = threadIdx.x;
-  const float s = 5.0f / (float)B;
-  __shared__ float sdl[HB_CHUNK][MAXA + 1];
-  if ((int)blockIdx.x < B) {
-    const int i = blockIdx.x;
-    if (tid == 0) {
-      float dl[MAXA], dv;
-      head_grad_row(probs + (long)i * A, values[i], actions[i], y[i], adv[i], beta, s, A, dl, &dv, nullptr);
-#pragma unroll
-      for (int a = 0; a < MAXA; ++a)
-        if (a < A) sdl[0][a] = dl[a];
-      sdl[0][MAXA] = dv;
-    }
-    __syncthreads();
-    for (int j = tid; j < H; j += 256) {
-      float acc = sdl[0][MAXA] * Wc[j];
-      for (int a = 0; a < A; ++a) acc += sdl[0][a] * Wa[j * A + a];
-      dH[(long)i * H + j] = h[(long)i * H + j] > 0.f ? acc : 0.f;
-    }
-    return;
-  }
-  const int role = blockIdx.x - B;
-  if (role < H / 32) {
-    const int jj = tid & 31, ig = tid >> 5;
-    const int j = role * 32 + jj;
-    float acc[MAXA + 1];
-#pragma unroll
-    for (int a = 0; a <= MAXA; ++a) acc[a] = 0.f;
-    for (int i0 = 0; i0 < B; i0 += HB_CHUNK) {
-      __syncthreads();
-      if (i0 + tid < B) {
-        const int i = i0 + tid;
-        float dl[MAXA], dv;
-        head_grad_row(probs + (long)i * A, values[i], actions[i], y[i], adv[i], beta, s, A, dl, &dv, nullptr);
-#pragma unroll
-        for (int a = 0; a < MAXA; ++a)
-          if (a < A) sdl[tid][a] = dl[a];
-        sdl[tid][MAXA] = dv;
-      }
-      __syncthreads();
-      const int cnt = min(HB_CHUNK, B - i0);
-#pragma unroll 4
-      for (int r = ig; r < cnt; r += 8) {
-        const float hv = h[(long)(i0 + r) * H + j];
-#pragma unroll
-        for (int a = 0; a < MAXA; ++a)
-          if (a < A) acc[a] += hv * sdl[r][a];
-        acc[MAXA] += hv * sdl[r][MAXA];
-      }
-    }
-    __syncthreads();
-    // reduce the 8 row-groups through LDS (reuse sdl: [8][32][MAXA+1] floats = 8448 <= 256*33)
-    float* redw = &sdl[0][0];
-#pragma unroll
-    for (int a = 0; a <= MAXA; ++a)
-      if (a < A || a == MAXA) redw[(ig * 32 + jj) * (MAXA + 1) + a] = acc[a];
-    __syncthreads();
-    for (int u = tid; u < 32 * (MAXA + 1); u += 256) {
-      const int c = u / (MAXA + 1), a = u % (MAXA + 1);
-      if (a < A || a == MAXA) {
-        float v = 0.f;
-#pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) v += redw[(g8 * 32 + c) * (MAXA + 1) + a];
-        const int jo = role * 32 + c;
-        if (a == MAXA) gWc[jo] = v;
-        else gWa[jo * A + a] = v;
-      }
-    }
-    return;
-  }
-  // bias gradients + loss scalars
-  float accb[MAXA + 1];
-  float st[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a <= MAXA; ++a) accb[a] = 0.f;
-  for (int i = tid; i < B; i += 256) {
-    float dl[MAXA], dv, stats[3];
-    head_grad_row(probs + (long)i * A, values[i], actions[i], y[i], adv[i], beta, s, A, dl, &dv, stats);
-#pragma unroll
-    for (int a = 0; a < MAXA; ++a)
-      if (a < A) accb[a] += dl[a];
-    accb[MAXA] += dv;
-    st[0] += stats[0]; st[1] += stats[1]; st[2] += stats[2];
-  }
-  __shared__ float red[4][MAXA + 4];
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int a = 0; a <= MAXA + 3; ++a) {
-    float v = (a <= MAXA) ? accb[a] : st[a - MAXA - 1];
-    if (a < A || a >= MAXA) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) red[wave][a] = v;
-    }
-  }
-  __syncthreads();
-  if (tid <= MAXA + 3 && (tid < A || tid >= MAXA)) {
-    const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (tid < A) gba[tid] = v;
-    else if (tid == MAXA) gbc[0] = v;
-    else if (loss_out) red[0][tid] = v;
-  }
-  __syncthreads();
-  if (tid == 0 && loss_out) {
-    const float actor = red[0][MAXA + 1] / (float)B;
-    const float critic = red[0][MAXA + 2] / (float)B;
-    loss_out[0] = 5.0f * (actor + critic);
-    loss_out[1] = actor;
-    loss_out[2] = critic;
-    loss_out[3] = red[0][MAXA + 3] / (float)B;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,9 +147,11 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinalizeArgs a
 
 // ---------------------------------------------------------------------------------------------
 template <class NT>
-static int forward_impl(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* logits,
+static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
                         float* probs, float* values, const PhiloxArgs& ph, hipStream_t s) {
   const paac_layout& L = ctx->layout;
+  Workspace& W = ctx->ws[wsi];
+  ctx->last_ws = wsi;
   const int A = ctx->cfg.num_actions;
   int t = 0;
   const float* w1 = params + L.offset[t++];
@@ -452,25 +173,25 @@ static int forward_impl(paac_ctx* ctx, const float* params, const uint8_t* state
 
   {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
-    GemmArgs g = make_args(states, w1, ctx->act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
+    GemmArgs g = make_args(states, w1, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
     launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, 1, s);
   }
   {
     ProfScope ps(ctx, F_CONV2_FWD, batch, s);
-    GemmArgs g = make_args(ctx->act[0], w2, ctx->act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
+    GemmArgs g = make_args(W.act[0], w2, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
     launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, 1, s);
   }
-  const float* last = ctx->act[1];
+  const float* last = W.act[1];
   if constexpr (NT::NCONV == 3) {
     ProfScope ps(ctx, F_CONV3_FWD, batch, s);
-    GemmArgs g = make_args(ctx->act[1], w3, ctx->act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
+    GemmArgs g = make_args(W.act[1], w3, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
     launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, 1, s);
-    last = ctx->act[2];
+    last = W.act[2];
   }
   int splits = 1;
   {
     ProfScope ps(ctx, F_FC_FWD, batch, s);
-    GemmArgs g = make_args(last, wf, ctx->fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
+    GemmArgs g = make_args(last, wf, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
     const long tiles = (long)((batch + 15) / 16) * (NT::H / 64);
     splits = pick_ksplit(tiles, 4, NT::FLAT / 16, FC_SPLITS_MAX, 768);
     g.slab_rows = batch;
@@ -478,9 +199,8 @@ static int forward_impl(paac_ctx* ctx, const float* params, const uint8_t* state
   }
   {
     ProfScope ps(ctx, F_HEADS_FWD, batch, s);
-    hipLaunchKernelGGL((heads_fwd_kernel<NT::H>), dim3(batch), dim3(256), 0, s, ctx->fc_slab, splits,
-                       (long)batch * NT::H, bf, wa, ba, wc, bc, A, ctx->h, ctx->logits, ctx->probs, ctx->values, logits,
-                       probs, values, ph);
+    launch_heads_fwd<NT::H>(A, dim3(batch), s, (const float*)W.fc_slab, splits, (long)batch * NT::H, bf, wa, ba, wc, bc,
+                            A, W.h, W.logits, W.probs, W.values, logits, probs, values, ph);
   }
   return 0;
 }
@@ -490,6 +210,9 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
                          const float* y, const float* adv, int batch, float beta, float* grad, float* loss_out,
                          hipStream_t s) {
   const paac_layout& L = ctx->layout;
+  Workspace& W = ctx->ws[1];
+  const bool forked = ctx->side != nullptr;
+  hipStream_t side = forked ? ctx->side : s;   // wgrads run here, concurrently with the dgrad chain on `s`
   const int A = ctx->cfg.num_actions;
   const int i_w1 = 0, i_w2 = 2, i_w3 = 4;
   const int i_wf = (NT::NCONV == 3) ? 6 : 4;
@@ -503,11 +226,11 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   // (1) heads: dH, head weight/bias grads, loss scalars
   {
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
-    hipLaunchKernelGGL((heads_bwd_kernel<NT::H>), dim3(batch + NT::H / 32 + 1), dim3(256), 0, s, ctx->probs,
-                       ctx->values, actions, y, adv, ctx->h, wa, wc, A, batch, beta, ctx->dh, grad + L.offset[i_wa],
-                       grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out);
+    launch_heads_bwd<NT::H>(A, dim3(batch + NT::H / 32 + 1), s, (const float*)W.probs, (const float*)W.values, actions, y,
+                            adv, (const float*)W.h, wa, wc, A, batch, beta, ctx->dh, grad + L.offset[i_wa],
+                            grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out);
   }
-  const float* xf = (NT::NCONV == 3) ? ctx->act[2] : ctx->act[1];   // flattened last conv output
+  const float* xf = (NT::NCONV == 3) ? W.act[2] : W.act[1];   // flattened last conv output
   float* dxf = (NT::NCONV == 3) ? ctx->dact[2] : ctx->dact[1];
   FinalizeArgs fin;
   memset(&fin, 0, sizeof(fin));
@@ -519,12 +242,16 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     fin.seg[fin.nseg++] = FinalizeSeg{base, grad + L.offset[i_w], feats * cout, splits, stride};
     fin.seg[fin.nseg++] = FinalizeSeg{base + (long)feats * cout, grad + L.offset[i_w + 1], cout, splits, stride};
   };
-  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b
+  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b   [side stream, needs dH]
+  if (forked) {
+    (void)hipEventRecord(ctx->ev_fork[0], s);
+    (void)hipStreamWaitEvent(side, ctx->ev_fork[0], 0);
+  }
   {
-    ProfScope ps(ctx, F_FC_WGRAD, batch, s);
+    ProfScope ps(ctx, F_FC_WGRAD, batch, side);
     GemmArgs g = make_args(xf, ctx->dh, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
     g.slab_rows = NT::FLAT + 1;
-    launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, s);
+    launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, side);
   }
   // (3) fc dgrad, masked by relu'(last conv output)
   {
@@ -534,39 +261,47 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, s);
   }
   if constexpr (NT::NCONV == 3) {
-    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3
+    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3   [side stream, needs dact[2] from fc dgrad]
+    if (forked) {
+      (void)hipEventRecord(ctx->ev_fork[1], s);
+      (void)hipStreamWaitEvent(side, ctx->ev_fork[1], 0);
+    }
     {
-      ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
+      ProfScope ps(ctx, F_CONV3_WGRAD, batch, side);
       const int feats = NT::G3::FEATS;
-      GemmArgs g = make_args(ctx->act[1], ctx->dact[2], slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
+      GemmArgs g = make_args(W.act[1], ctx->dact[2], slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
       g.slab_rows = feats + 1;
-      const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, s);
+      const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, side);
       wgrad_out(i_w3, feats, NT::C3, slab, splits);
       slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
     }
     // (5) conv3 dgrad -> dact[1] masked by relu'(a2)
     {
       ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
-      GemmArgs g = make_args(ctx->dact[2], w3, ctx->dact[1], ctx->act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
+      GemmArgs g = make_args(ctx->dact[2], w3, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
       for (int kh = 0; kh < 3; ++kh)
         for (int kw = 0; kw < 3; ++kw) g.tapoff[0][kh * 3 + kw] = ((2 - kh) * 3 + (2 - kw)) * NT::C2 * NT::C3;
       launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, s);
     }
   }
-  // (6) conv2 wgrad
+  // (6) conv2 wgrad   [side stream, needs dact[1]]
+  if (forked) {
+    (void)hipEventRecord(ctx->ev_fork[2], s);
+    (void)hipStreamWaitEvent(side, ctx->ev_fork[2], 0);
+  }
   {
-    ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
+    ProfScope ps(ctx, F_CONV2_WGRAD, batch, side);
     const int feats = NT::G2::FEATS;
-    GemmArgs g = make_args(ctx->act[0], ctx->dact[1], slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
+    GemmArgs g = make_args(W.act[0], ctx->dact[1], slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
     g.slab_rows = feats + 1;
-    const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, s);
+    const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, side);
     wgrad_out(i_w2, feats, NT::C2, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C2;
   }
   // (7) conv2 dgrad by output parity (4 classes in blockIdx.z) -> dact[0] masked by relu'(a1)
   {
     ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
-    GemmArgs g = make_args(ctx->dact[1], w2, ctx->dact[0], ctx->act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
+    GemmArgs g = make_args(ctx->dact[1], w2, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
     for (int par = 0; par < 4; ++par) {
       const int py = par >> 1, px = par & 1;
       for (int kh = 0; kh < 2; ++kh)
@@ -584,6 +319,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, s);
     wgrad_out(i_w1, feats, NT::C1, slab, splits);
   }
+  if (forked) {
+    (void)hipEventRecord(ctx->ev_join, side);
+    (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
+  }
   {
     ProfScope ps(ctx, F_GRAD_FINALIZE, batch, s);
     int maxcount = 0;
@@ -593,13 +332,13 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   return 0;
 }
 
-int launch_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, bool, float* logits,
+int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,
                    float* probs, float* values, hipStream_t s) {
   PhiloxArgs ph;
   memset(&ph, 0, sizeof(ph));
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, params, states, batch, logits, probs, values, ph, s);
-  return forward_impl<NipsNet>(ctx, params, states, batch, logits, probs, values, ph, s);
+    return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
+  return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
 }
 
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
@@ -613,8 +352,8 @@ int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* sta
   ph.env_offset = env_offset;
   ph.actions = actions;
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, params, states, batch, nullptr, probs, values, ph, s);
-  return forward_impl<NipsNet>(ctx, params, states, batch, nullptr, probs, values, ph, s);
+    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
+  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
 }
 
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
@@ -623,6 +362,12 @@ int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, c
     return backward_impl<NatureNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, s);
   return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, s);
 }
+
+#ifdef PAAC_DMM_STAMPS
+extern "C" void paac_debug_set_heads_stamps(unsigned long long* p) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_dev), &p, sizeof(p));
+}
+#endif
 
 int64_t wslab_floats_needed(int arch) {
   if (arch == PAAC_ARCH_NATURE)

@@ -92,7 +92,17 @@ class Context(object):
                                                 int(env_offset), _ptr(actions, torch.int32, B, "actions"), _stream()),
                    "paac_forward_sample")
 
-    def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None):
+    def train_forward(self, params, states):
+        B = states.shape[0]
+        if tuple(states.shape[1:]) != OBS_SHAPE:
+            raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
+        if not (0 < B <= self.max_batch):
+            raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
+        _lib.check(self.lib.paac_train_forward(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                               _ptr(states, torch.uint8, B * 28224, "states"), B, _stream()),
+                   "paac_train_forward")
+
+    def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None, forward_done=False):
         B = states.shape[0]
         if tuple(states.shape[1:]) != OBS_SHAPE:
             raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
@@ -104,7 +114,8 @@ class Context(object):
                                                _ptr(y, torch.float32, B, "y"), _ptr(adv, torch.float32, B, "adv"), B,
                                                float(entropy_beta),
                                                _ptr(grad, torch.float32, self.layout["total"], "grad"),
-                                               _ptr(loss_out, torch.float32, 4, "loss_out", True), _stream()),
+                                               _ptr(loss_out, torch.float32, 4, "loss_out", True),
+                                               1 if forward_done else 0, _stream()),
                    "paac_loss_backward")
 
     def clip_rmsprop(self, params, grad, ms, mom, lr_dev, decay, momentum, eps, clip_norm, clip_mode, grad_scale=1.0,
@@ -154,6 +165,21 @@ def nstep_returns(v_boot, rewards, masks, values, gamma, y, adv):
                                       _ptr(masks, torch.float32, T * N, "masks"), _ptr(values, torch.float32, T * N, "values"),
                                       T, N, float(gamma), _ptr(y, torch.float32, T * N, "y"),
                                       _ptr(adv, torch.float32, T * N, "adv"), _stream()), "paac_nstep_returns")
+
+
+def nstep_returns_tick(v_boot, rewards, masks, values, gamma, y, adv, global_step_dev, increment, initial_lr,
+                       lr_annealing_steps, lr_out_dev, tick_dev=None, tick_inc=0):
+    T, N = rewards.shape
+    lib = _lib.load()
+    _lib.check(lib.paac_nstep_returns_tick(_ptr(v_boot, torch.float32, N, "v_boot"), _ptr(rewards, torch.float32, T * N, "rewards"),
+                                           _ptr(masks, torch.float32, T * N, "masks"), _ptr(values, torch.float32, T * N, "values"),
+                                           T, N, float(gamma), _ptr(y, torch.float32, T * N, "y"),
+                                           _ptr(adv, torch.float32, T * N, "adv"),
+                                           _ptr(global_step_dev, torch.int64, 1, "global_step"), int(increment),
+                                           float(initial_lr), int(lr_annealing_steps),
+                                           _ptr(lr_out_dev, torch.float32, 1, "lr_out"),
+                                           _ptr(tick_dev, torch.int64, 1, "tick", True), int(tick_inc), _stream()),
+               "paac_nstep_returns_tick")
 
 
 def sample_mt_scratch(N, A, device):

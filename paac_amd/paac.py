@@ -82,14 +82,15 @@ class DeviceRollout(object):
                                self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
                                raw_scratch=self.raw)
         L.ctx.forward(params, self.states[T], values=self.v_boot)                     # paac.py:140-142
-        hip_ops.nstep_returns(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv)
+        # returns + global_step/lr schedule + frame counter in one launch (paac.py:127,144-156)
+        hip_ops.nstep_returns_tick(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv,
+                                   self.global_step_dev, self.total_envs * T, L.initial_lr, L.lr_annealing_steps,
+                                   L.lr_dev, self.tick, T)
         L.ctx.loss_backward(params, self.states[:T].view(T * N, 84, 84, 4), self.actions.view(-1), self.y, self.adv,
                             L.entropy_beta, L.grad, L.loss_dev)
 
     def _update(self):
         L = self.L
-        hip_ops.lr_step(self.global_step_dev, self.total_envs * self.T, L.initial_lr, L.lr_annealing_steps, L.lr_dev)
-        hip_ops.counter_add(self.tick, self.T)
         L.ctx.clip_rmsprop(L.network.params, L.grad, L.rms, L.mom, L.lr_dev, L.alpha, L.momentum, L.e, L.clip_norm,
                            L.clip_mode, L._grad_scale(), L.gnorm_dev)
 
