@@ -8,7 +8,7 @@
 
 namespace paac {
 
-constexpr int FC_SPLITS_MAX = 4;   // fc forward split-K slabs (summed here)
+constexpr int FC_SPLITS_MAX = 8;   // fc forward split-K slabs (summed here)
 constexpr int MAXA = 32;
 
 #ifdef PAAC_DMM_STAMPS

@@ -3,6 +3,8 @@
 //   optimizer.compute_gradients(loss) builds from them (actor_learner.py:44).
 // Layout contract: activations NHWC fp32, conv weights HWIO, fc weights [in,out], flatten in HWC order
 // (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
+#include <stdlib.h>
+
 #include "dmm.h"
 #include "heads.h"
 
@@ -31,7 +33,7 @@ struct NipsNet {
   using G2D = Geom<9, 9, 32, 10, 10, 1, 1, 1, 2, 2>;
 };
 
-constexpr int W_SPLITS_MAX = 64;
+constexpr int W_SPLITS_MAX = 192;
 
 #ifdef PAAC_DMM_STAMPS
 unsigned long long* g_stamps = nullptr;   // diagnostic build: the `which`-th dmm launch after the call is stamped
@@ -58,7 +60,14 @@ static GemmArgs make_args(const void* A, const float* B, float* out, const float
 }
 
 // blockIdx.z split of K so that the launch has about `target_waves` waves.
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int target_waves = 1024) {
+  static const int scale_pct = env_int("PAAC_TUNE_WAVES_PCT", 100);   // tuning knob (diagnostics)
+  target_waves = target_waves * scale_pct / 100;
   long s = (target_waves + tiles * wk - 1) / (tiles * wk);
   if (s > max_split) s = max_split;
   if (s > ngroups / wk) s = ngroups / wk;

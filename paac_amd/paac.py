@@ -38,7 +38,10 @@ class DeviceRollout(object):
         self.sampler = sampler
         self.sampler_seed = int(sampler_seed)
         self.use_graph = use_graph
-        self.states = torch.zeros((T + 1, N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        # Observation ring of 2T slots: even cycles use slots 0..T, odd cycles T..2T (slot 2T == slot 0), so the
+        # last observation of a cycle IS the first of the next one without a copy; two captured graphs alternate.
+        self.states = torch.zeros((2 * T, N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        self.parity = 0
         self.actions = torch.zeros((T, N), dtype=torch.int32, device=dev)
         self.values = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.rewards = torch.zeros((T, N), dtype=torch.float32, device=dev)
@@ -59,34 +62,42 @@ class DeviceRollout(object):
             self.mt_state = hip_ops.mt_state_from_numpy(np.random.get_state(), dev)
             self.mt_scratch = hip_ops.sample_mt_scratch(N, A, dev)
         self.stream = torch.cuda.Stream(device=dev)
-        self.graph_a = None
+        self.graph_a = [None, None]
         self.graph_b = None
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
-        self.states[T].copy_(self.states[0])
         torch.cuda.synchronize(dev)
 
     # -- stages --------------------------------------------------------------------------------------
-    def _rollout_and_backward(self):
+    def _slot(self, parity, t):
+        return (parity * self.T + t) % (2 * self.T)
+
+    def rollout_states(self, parity=None):
+        """[T*N,84,84,4] view of the states the LAST run cycle trained on (t-major, paac.py:151)."""
+        parity = (self.parity ^ 1) if parity is None else parity
+        T, N = self.T, self.N
+        return self.states[parity * T:(parity + 1) * T].view(T * N, 84, 84, 4)
+
+    def _rollout_and_backward(self, parity):
         L, T, N = self.L, self.T, self.N
         params = L.network.params
-        self.states[0].copy_(self.states[T])                      # carry the last observation over
+        st = [self.states[self._slot(parity, t)] for t in range(T + 1)]
         for t in range(T):
             if self.sampler == "numpy":
-                L.ctx.forward(params, self.states[t], probs=self.probs, values=self.values[t])
+                L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
                 hip_ops.sample_mt(self.probs, self.mt_state, self.mt_scratch, self.actions[t])
             else:       # counter-based sampler fused into the heads kernel
-                L.ctx.forward_sample(params, self.states[t], self.sampler_seed, self.tick, t, self.env_offset,
+                L.ctx.forward_sample(params, st[t], self.sampler_seed, self.tick, t, self.env_offset,
                                      self.actions[t], probs=self.probs, values=self.values[t])
             hip_ops.synth_step(self.env_spec["seed"], self.env_offset, self.actions[t],
-                               self.env_spec["terminal_threshold"], self.tick, t, self.states[t], self.states[t + 1],
+                               self.env_spec["terminal_threshold"], self.tick, t, st[t], st[t + 1],
                                self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
                                raw_scratch=self.raw)
-        L.ctx.forward(params, self.states[T], values=self.v_boot)                     # paac.py:140-142
+        L.ctx.forward(params, st[T], values=self.v_boot)                              # paac.py:140-142
         # returns + global_step/lr schedule + frame counter in one launch (paac.py:127,144-156)
         hip_ops.nstep_returns_tick(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv,
                                    self.global_step_dev, self.total_envs * T, L.initial_lr, L.lr_annealing_steps,
                                    L.lr_dev, self.tick, T)
-        L.ctx.loss_backward(params, self.states[:T].view(T * N, 84, 84, 4), self.actions.view(-1), self.y, self.adv,
+        L.ctx.loss_backward(params, self.rollout_states(parity), self.actions.view(-1), self.y, self.adv,
                             L.entropy_beta, L.grad, L.loss_dev)
 
     def _update(self):
@@ -95,16 +106,18 @@ class DeviceRollout(object):
                            L.clip_mode, L._grad_scale(), L.gnorm_dev)
 
     def capture(self):
-        """Capture the cycle into hipGraphs (two halves when a gradient all-reduce sits between them)."""
+        """Capture the cycle into hipGraphs: one per observation-ring parity (and a separate update graph when a
+        gradient all-reduce sits between backward and the optimizer step)."""
         with torch.cuda.stream(self.stream):
             world = self.L._world()
-            ga = hip_ops.Graph()
-            ga.begin()
-            self._rollout_and_backward()
-            if world == 1:
-                self._update()
-            ga.end()
-            self.graph_a = ga
+            for parity in (0, 1):
+                ga = hip_ops.Graph()
+                ga.begin()
+                self._rollout_and_backward(parity)
+                if world == 1:
+                    self._update()
+                ga.end()
+                self.graph_a[parity] = ga
             if world > 1:
                 gb = hip_ops.Graph()
                 gb.begin()
@@ -115,16 +128,17 @@ class DeviceRollout(object):
     def run_cycle(self):
         with torch.cuda.stream(self.stream):
             if self.use_graph:
-                if self.graph_a is None:
+                if self.graph_a[0] is None:
                     self.capture()
-                self.graph_a.launch()
+                self.graph_a[self.parity].launch()
                 if self.graph_b is not None:
                     self.L._allreduce_grad()
                     self.graph_b.launch()
             else:
-                self._rollout_and_backward()
+                self._rollout_and_backward(self.parity)
                 self.L._allreduce_grad()
                 self._update()
+        self.parity ^= 1
 
     def synchronize(self):
         self.stream.synchronize()
@@ -140,10 +154,11 @@ class DeviceRollout(object):
         return count, [(float(rewards[i]), int(lens[i])) for i in idx]
 
     def close(self):
-        for g in (self.graph_a, self.graph_b):
+        for g in (self.graph_a[0], self.graph_a[1], self.graph_b):
             if g is not None:
                 g.close()
-        self.graph_a = self.graph_b = None
+        self.graph_a = [None, None]
+        self.graph_b = None
 
 
 class PAACLearner(ActorLearner):

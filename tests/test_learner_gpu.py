@@ -115,7 +115,7 @@ def test_device_loop_matches_host_loop(raw_frames, use_graph):
     for c in range(cycles):
         ro.run_cycle()
         ro.synchronize()
-        assert np.array_equal(ro.states[:T].reshape(T * N, 84, 84, 4).cpu().numpy(), feeds[c]["states"]), "cycle %d" % c
+        assert np.array_equal(ro.rollout_states().cpu().numpy(), feeds[c]["states"]), "cycle %d" % c
         assert np.array_equal(ro.actions.view(-1).cpu().numpy(), feeds[c]["actions"])
         assert np.allclose(ro.y.cpu().numpy(), feeds[c]["y"], atol=1e-5)
         assert abs(devl.lr_dev.item() - np.float32(feeds[c]["lr"])) == 0.0
