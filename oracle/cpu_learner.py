@@ -70,8 +70,15 @@ def run(envs, arch, num_actions, T, params, min_seconds=10.0, warmup_cycles=2, s
     """Time the port.  Returns dict(steps_per_s, cycles, seconds, cores)."""
     net = TorchNet(arch, num_actions, params)
     rs = np.random.RandomState(seed)
-    ro = oroll.OracleRollout(envs, num_actions, T, gamma, initial_lr, lr_annealing_steps, net.policy,
-                             lambda pi: osamp.sample_numpy_reference(pi, rs))
+    def sample(pi):
+        # paac.py:42-44 verbatim; modern numpy rejects p - epsneg < 0 (a saturated policy on the noise frames),
+        # where 2017-era numpy drew and never selected the category -> fall back to the restatement with that behaviour.
+        try:
+            return osamp.sample_numpy_reference(pi, rs)
+        except ValueError:
+            return osamp.sample_mt_restated(pi, rs)[0]
+
+    ro = oroll.OracleRollout(envs, num_actions, T, gamma, initial_lr, lr_annealing_steps, net.policy, sample)
     N = len(envs)
 
     def one_cycle():

@@ -38,6 +38,7 @@ ArchSpec arch_spec(int arch) {
 }
 
 int64_t wslab_floats_needed(int arch);
+void default_tuning(paac_ctx* c);
 int fc_splits_max();
 
 static const char* kFamilyNames[PAAC_PROF_FAMILIES] = {
@@ -122,6 +123,9 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   }
   c->spec = arch_spec(cfg->arch);
   c->max_batch = cfg->max_batch;
+  for (int o = 0; o < OP_COUNT; ++o)
+    for (int k = 0; k < 2; ++k) c->tune[o][k] = Tune{-1, 0, -1};
+  default_tuning(c);
   const int64_t B = cfg->max_batch;
   const int A = cfg->num_actions;
   c->fc_splits_max = fc_splits_max();
@@ -276,6 +280,12 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
   }
   PAAC_CHECK_HIP(hipMemcpyAsync(out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return n;
+}
+
+int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int ksplit, int xcd_dim) {
+  PAAC_REQUIRE(ctx && op >= 0 && op < OP_COUNT && (batch_class == 0 || batch_class == 1), "paac_debug_set_tuning: bad op/class");
+  ctx->tune[op][batch_class] = Tune{cfg, ksplit, xcd_dim};
+  return 0;
 }
 
 // ---- hipGraph helpers -------------------------------------------------------------------------

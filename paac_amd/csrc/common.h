@@ -67,8 +67,20 @@ struct Workspace {
 };
 }  // namespace paac
 
+namespace paac {
+// GEMM ops of the network (tuning table index) and their launch tuning record.
+enum Op { OP_CONV1_FWD = 0, OP_CONV2_FWD, OP_CONV3_FWD, OP_FC_FWD, OP_FC_WGRAD, OP_FC_DGRAD, OP_CONV3_WGRAD,
+          OP_CONV3_DGRAD, OP_CONV2_WGRAD, OP_CONV2_DGRAD, OP_CONV1_WGRAD, OP_COUNT };
+struct Tune {
+  int cfg;     // index into the family's configuration table, -1 = size heuristic
+  int ksplit;  // blockIdx.z K split (slab epilogues), 0 = heuristic
+  int xcd;     // grid dimension tied to the XCD (0 M tiles, 1 N tiles, 2 z), -1 none
+};
+}  // namespace paac
+
 struct paac_ctx {
   paac_cfg cfg;
+  paac::Tune tune[paac::OP_COUNT][2];   // [op][batch class: 0 = batch <= 64, 1 = larger]
   paac::ArchSpec spec;
   paac_layout layout;
   int max_batch;

@@ -22,6 +22,8 @@
 //   * Epilogues: bias+ReLU, raw split-K slab (+ bias-gradient row for wgrad), ReLU-mask (dgrad) with the
 //     stride-2 parity scatter.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace paac {
@@ -51,6 +53,12 @@ struct GemmArgs {
   int groups_per_part;    // 16-wide K groups per (blockIdx.z, wk) part
   int slab_rows;          // EPI_SLAB: rows per slab (M, or M+1 with the bias-gradient row)
   int tapoff[4][9];       // FRAG_K B: element offset of each (parity, tap)
+  // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8;
+  // observed, used for speed only) and every XCD has its own L2, which a kernel boundary leaves cold: an operand
+  // slice read by workgroups on k different XCDs is fetched from the Infinity Cache k times.  xcd_dim names the
+  // grid dimension (0 = M tiles, 1 = N tiles, 2 = z) whose index is tied to the XCD, so that all workgroups that
+  // share the big operand slice of one index run on one XCD; -1 = plain (x fastest) order.
+  int MT, NT, Z, xcd_dim;
 #ifdef PAAC_DMM_STAMPS
   unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave
 #endif
@@ -61,7 +69,7 @@ struct GemmArgs {
   do {                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     if (p.stamps && lane == 0)                                                                \
-      p.stamps[((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NWM * NWN * WK) + wave) * 8 + (i)] = \
+      p.stamps[((long)blockIdx.x * (NWM * NWN * WK) + wave) * 8 + (i)] = \
           ((i) == 0 || (i) == 7) ? (unsigned long long)wall_clock64() : (unsigned long long)clock64();                          \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   } while (0)
@@ -128,9 +136,41 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
   const int wm = wave / (WK * NWN);
   const int li = lane & 15;   // row / column inside a tile
   const int kq = lane >> 4;   // k-slot
-  const int z = blockIdx.z;
-  const int m0 = (blockIdx.x * NWM + wm) * (TM * 16);
-  const int n0 = (blockIdx.y * NWN + wn) * (TN * 16);
+  int bx, by, bz;
+  {
+    const int bid = blockIdx.x;
+    if (p.xcd_dim < 0) {
+      bx = bid % p.MT;
+      const int r = bid / p.MT;
+      by = r % p.NT;
+      bz = r / p.NT;
+    } else {
+      const int xcd = bid & 7, l = bid >> 3;
+      if (p.xcd_dim == 2) {
+        const int per = p.MT * p.NT;
+        bz = xcd + 8 * (l / per);
+        const int r = l % per;
+        bx = r % p.MT;
+        by = r / p.MT;
+      } else if (p.xcd_dim == 1) {
+        const int per = p.MT * p.Z;
+        by = xcd + 8 * (l / per);
+        const int r = l % per;
+        bx = r % p.MT;
+        bz = r / p.MT;
+      } else {
+        const int per = p.NT * p.Z;
+        bx = xcd + 8 * (l / per);
+        const int r = l % per;
+        by = r % p.NT;
+        bz = r / p.NT;
+      }
+      if (bx >= p.MT || by >= p.NT || bz >= p.Z) return;   // padding blocks of the 8-way split
+    }
+  }
+  const int z = bz;
+  const int m0 = (bx * NWM + wm) * (TM * 16);
+  const int n0 = (by * NWN + wn) * (TN * 16);
   const int par = (EPI == EPI_MASK_PARITY) ? z : 0;
   DMM_STAMP(0);
   DMM_STAMP(1);
@@ -352,7 +392,7 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
   DMM_STAMP(7);
   // ---- bias-gradient row: column sums of dY over this part's K range ------------------------------------
   if constexpr (BIASROW) {
-    if (blockIdx.x == 0 && wm == 0) {
+    if (bx == 0 && wm == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float v = bsum[c];
@@ -379,12 +419,21 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
 
 template <class G, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI, bool BIASROW,
           int PF>
-inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, hipStream_t s) {
+inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, int xcd_dim, hipStream_t s) {
   const int ngroups = (a.K + 15) / 16;
   const int parts = WK * ((EPI == EPI_SLAB) ? ksplit_z : 1);
   a.groups_per_part = (ngroups + parts - 1) / parts;
-  dim3 grid((a.M + NWM * TM * 16 - 1) / (NWM * TM * 16), (a.N + NWN * TN * 16 - 1) / (NWN * TN * 16), zdim);
-  hipLaunchKernelGGL((dmm_kernel<G, U8, AP, BP, TM, TN, NWM, NWN, WK, BCO, EPI, BIASROW, PF>), grid,
+  a.MT = (a.M + NWM * TM * 16 - 1) / (NWM * TM * 16);
+  a.NT = (a.N + NWN * TN * 16 - 1) / (NWN * TN * 16);
+  a.Z = zdim;
+  static const int xcd_mask = []() { const char* v = getenv("PAAC_TUNE_XCD"); return (v && *v) ? atoi(v) : 7; }();
+  a.xcd_dim = (xcd_dim >= 0 && ((xcd_mask >> xcd_dim) & 1)) ? xcd_dim : -1;   // tuning knob: bit d enables dim d
+  xcd_dim = a.xcd_dim;
+  long blocks = (long)a.MT * a.NT * a.Z;
+  if (xcd_dim == 0) blocks = (long)((a.MT + 7) / 8) * 8 * a.NT * a.Z;
+  if (xcd_dim == 1) blocks = (long)((a.NT + 7) / 8) * 8 * a.MT * a.Z;
+  if (xcd_dim == 2) blocks = (long)((a.Z + 7) / 8) * 8 * a.MT * a.NT;
+  hipLaunchKernelGGL((dmm_kernel<G, U8, AP, BP, TM, TN, NWM, NWN, WK, BCO, EPI, BIASROW, PF>), dim3((unsigned)blocks),
                      dim3(64 * NWM * NWN * WK), 0, s, a);
 }
 

@@ -33,7 +33,7 @@ struct NipsNet {
   using G2D = Geom<9, 9, 32, 10, 10, 1, 1, 1, 2, 2>;
 };
 
-constexpr int W_SPLITS_MAX = 192;
+constexpr int W_SPLITS_MAX = 64;
 
 #ifdef PAAC_DMM_STAMPS
 unsigned long long* g_stamps = nullptr;   // diagnostic build: the `which`-th dmm launch after the call is stamped
@@ -45,6 +45,11 @@ extern "C" void paac_debug_set_stamps(unsigned long long* p, int which) {
   g_stamp_calls = 0;
 }
 #endif
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 
 static GemmArgs make_args(const void* A, const float* B, float* out, const float* aux, int M, int N, int K, int ldb,
                           int ldo) {
@@ -60,14 +65,7 @@ static GemmArgs make_args(const void* A, const float* B, float* out, const float
 }
 
 // blockIdx.z split of K so that the launch has about `target_waves` waves.
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int target_waves = 1024) {
-  static const int scale_pct = env_int("PAAC_TUNE_WAVES_PCT", 100);   // tuning knob (diagnostics)
-  target_waves = target_waves * scale_pct / 100;
   long s = (target_waves + tiles * wk - 1) / (tiles * wk);
   if (s > max_split) s = max_split;
   if (s > ngroups / wk) s = ngroups / wk;
@@ -77,50 +75,98 @@ static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int targe
   return (int)s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Launch configurations.  Each GEMM family has a small table of (tiles per wave, waves per workgroup, K split over
+// waves, prefetch depth) instantiations; a Tune record (per op and batch class, set from measured sweeps --
+// tools/tune_gemm.py -- or left at cfg = -1 for the size heuristic) picks one, plus the blockIdx.z K split and the
+// XCD-tied grid dimension.
+//                      id TM NWM WK PF
+#define PAAC_FWD_CFGS(X) X(0, 1, 1, 8, 5) X(1, 1, 1, 4, 5) X(2, 2, 1, 8, 3) X(3, 2, 1, 4, 3) X(4, 2, 2, 2, 2) \
+                         X(5, 2, 4, 1, 2) X(6, 1, 2, 4, 4) X(7, 2, 2, 4, 2)
+#define PAAC_DGRAD_CFGS(X) X(0, 1, 1, 8, 4) X(1, 2, 1, 4, 4) X(2, 2, 2, 2, 3) X(3, 2, 4, 1, 2) X(4, 1, 1, 4, 4) \
+                           X(5, 2, 1, 8, 3) X(6, 1, 2, 4, 4)
+//                        id TM WK PF
+#define PAAC_WGRAD_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(2, 4, 8, 2) X(3, 4, 4, 3) X(4, 2, 4, 3) X(5, 2, 8, 3)
+constexpr int kFwdCfgs = 8, kDgradCfgs = 7, kWgradCfgs = 6;
+
 // Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
 template <class G, bool U8, int NDIM, int EPI>
-static void launch_fwd(const GemmArgs& g, int ksplit, hipStream_t s) {
+static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
   constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
-  const long rows16 = (g.M + 15) / 16;
-  const long ncol = (g.N + 16 * VN - 1) / (16 * VN);
-  if (rows16 * ncol * ksplit <= 256) {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 1, VN, 1, 1, 8, 1, EPI, false, 5>(g, ksplit, ksplit, s);   // 16 rows, K over 8 waves
-  } else if (rows16 * ncol * ksplit <= 1024) {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 1, 1, 4, 1, EPI, false, 3>(g, ksplit, ksplit, s);   // 32 rows, K over 4 waves
-  } else if (rows16 * ncol * ksplit <= 4096) {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 2, 1, 2, 1, EPI, false, 2>(g, ksplit, ksplit, s);   // 64 rows, K over 2 waves
-  } else {
-    launch_dmm<G, U8, FRAG_K, FRAG_MN, 2, VN, 4, 1, 1, 1, EPI, false, 2>(g, ksplit, ksplit, s);   // 128 rows, no K split
+  int cfg = t.cfg, ksplit = 1, xcd = t.xcd;
+  if constexpr (EPI == EPI_SLAB) {
+    ksplit = t.ksplit > 0 ? t.ksplit : 0;
+    if (ksplit <= 0) {   // heuristic: fill ~768 waves
+      const long tiles = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN));
+      ksplit = pick_ksplit(tiles, 4, (g.K + 15) / 16, FC_SPLITS_MAX, 768);
+    }
+    if (ksplit > FC_SPLITS_MAX) ksplit = FC_SPLITS_MAX;
   }
+  if (cfg < 0) {
+    const long w = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN)) * ksplit;
+    cfg = (w <= 256) ? 0 : (w <= 1024) ? 3 : (w <= 4096) ? 4 : 5;
+    xcd = -1;
+  }
+  switch (cfg) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF>(g, ksplit, ksplit, xcd, s); break;
+    PAAC_FWD_CFGS(X)
+#undef X
+    default: break;
+  }
+  return ksplit;
 }
 
 // dgrad: A = FRAG_K patches of dY, B = FRAG_K taps of W^T.
 template <class G, int NDIM, int BCO, int EPI>
-static void launch_dgrad(const GemmArgs& g, int zdim, hipStream_t s) {
+static void launch_dgrad(const GemmArgs& g, int zdim, Tune t, hipStream_t s) {
   constexpr int TN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
-  const long tiles = (long)((g.M + 31) / 32) * ((g.N + 16 * TN - 1) / (16 * TN)) * zdim;
-  if (tiles <= 384) {
-    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 1, 1, 4, BCO, EPI, false, 4>(g, zdim, 1, s);
-  } else if (tiles <= 1536) {
-    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 2, 1, 2, BCO, EPI, false, 3>(g, zdim, 1, s);
-  } else {
-    launch_dmm<G, false, FRAG_K, FRAG_K, 2, TN, 4, 1, 1, BCO, EPI, false, 2>(g, zdim, 1, s);
+  int cfg = t.cfg, xcd = t.xcd;
+  if (cfg < 0) {
+    const long tiles = (long)((g.M + 31) / 32) * ((g.N + 16 * TN - 1) / (16 * TN)) * zdim;
+    cfg = (tiles <= 384) ? 1 : (tiles <= 1536) ? 2 : 3;
+    xcd = (EPI == EPI_MASK_PARITY) ? 0 : -1;
+  }
+  switch (cfg) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<G, false, FRAG_K, FRAG_K, TM, TN, NWM, 1, WK, BCO, EPI, false, PF>(g, zdim, 1, xcd, s); break;
+    PAAC_DGRAD_CFGS(X)
+#undef X
+    default: break;
   }
 }
 
-// wgrad: A = FRAG_MN patches^T (64 features per wave), B = FRAG_MN dY; split-K slabs + bias-gradient row.
+// wgrad: A = FRAG_MN patches^T (16*TM features per wave), B = FRAG_MN dY; split-K slabs + bias-gradient row.
 template <class G, bool U8, int NDIM>
-static int launch_wgrad(GemmArgs g, int max_split, hipStream_t s) {
+static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s) {
   constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
-  const long tiles = (long)((g.M + 63) / 64) * ((g.N + 16 * VN - 1) / (16 * VN));
   const int ngroups = (g.K + 15) / 16;
-  if (ngroups >= 32) {
-    const int ks = pick_ksplit(tiles, 4, ngroups, max_split);
-    launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 4, 1, EPI_SLAB, true, 2>(g, ks, ks, s);
-    return ks;
+  int cfg = t.cfg, ks = t.ksplit, xcd = t.xcd;
+  if (cfg < 0) {
+    const long tiles = (long)((g.M + 63) / 64) * ((g.N + 16 * VN - 1) / (16 * VN));
+    if (ngroups >= 64 && max_split >= 8) {
+      cfg = 0;
+      ks = (pick_ksplit(tiles, 4, ngroups, max_split) + 7) / 8 * 8;   // multiple of 8: one K range per XCD
+      xcd = 2;
+    } else {
+      cfg = 1;
+      ks = 1;
+      xcd = -1;
+    }
   }
-  const int ks = 1;
-  launch_dmm<G, U8, FRAG_MN, FRAG_MN, 4, VN, 1, 1, 2, 1, EPI_SLAB, true, 2>(g, ks, ks, s);
+  if (ks < 1) ks = 1;
+  if (ks > max_split) ks = max_split;
+  if (U8 && (cfg == 4 || cfg == 5)) cfg = 0;   // u8 patches are loaded as uchar4: 64 features per wave only
+  switch (cfg) {
+#define X(id, TM, WK, PF)                                                                                     \
+  case id:                                                                                                    \
+    if constexpr (!U8 || TM == 4)                                                                             \
+      launch_dmm<G, U8, FRAG_MN, FRAG_MN, TM, VN, 1, 1, WK, 1, EPI_SLAB, true, PF>(g, ks, ks, xcd, s);        \
+    break;
+    PAAC_WGRAD_CFGS(X)
+#undef X
+    default: break;
+  }
   return ks;
 }
 
@@ -161,6 +207,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[wsi];
   ctx->last_ws = wsi;
+  const int cls = batch > 64 ? 1 : 0;
   const int A = ctx->cfg.num_actions;
   int t = 0;
   const float* w1 = params + L.offset[t++];
@@ -183,28 +230,26 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
     GemmArgs g = make_args(states, w1, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
-    launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, 1, s);
+    launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
   }
   {
     ProfScope ps(ctx, F_CONV2_FWD, batch, s);
     GemmArgs g = make_args(W.act[0], w2, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
-    launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, 1, s);
+    launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
   }
   const float* last = W.act[1];
   if constexpr (NT::NCONV == 3) {
     ProfScope ps(ctx, F_CONV3_FWD, batch, s);
     GemmArgs g = make_args(W.act[1], w3, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
-    launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, 1, s);
+    launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);
     last = W.act[2];
   }
   int splits = 1;
   {
     ProfScope ps(ctx, F_FC_FWD, batch, s);
     GemmArgs g = make_args(last, wf, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
-    const long tiles = (long)((batch + 15) / 16) * (NT::H / 64);
-    splits = pick_ksplit(tiles, 4, NT::FLAT / 16, FC_SPLITS_MAX, 768);
     g.slab_rows = batch;
-    launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, splits, s);
+    splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
   }
   {
     ProfScope ps(ctx, F_HEADS_FWD, batch, s);
@@ -220,6 +265,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
                          hipStream_t s) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[1];
+  const int cls = batch > 64 ? 1 : 0;
   const bool forked = ctx->side != nullptr;
   hipStream_t side = forked ? ctx->side : s;   // wgrads run here, concurrently with the dgrad chain on `s`
   const int A = ctx->cfg.num_actions;
@@ -260,14 +306,14 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     ProfScope ps(ctx, F_FC_WGRAD, batch, side);
     GemmArgs g = make_args(xf, ctx->dh, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
     g.slab_rows = NT::FLAT + 1;
-    launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, side);
+    launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, ctx->tune[OP_FC_WGRAD][cls], side);
   }
   // (3) fc dgrad, masked by relu'(last conv output)
   {
     ProfScope ps(ctx, F_FC_DGRAD, batch, s);
     GemmArgs g = make_args(ctx->dh, wf, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
     g.tapoff[0][0] = 0;
-    launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, s);
+    launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, ctx->tune[OP_FC_DGRAD][cls], s);
   }
   if constexpr (NT::NCONV == 3) {
     // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3   [side stream, needs dact[2] from fc dgrad]
@@ -280,7 +326,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       const int feats = NT::G3::FEATS;
       GemmArgs g = make_args(W.act[1], ctx->dact[2], slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
       g.slab_rows = feats + 1;
-      const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, side);
+      const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], side);
       wgrad_out(i_w3, feats, NT::C3, slab, splits);
       slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
     }
@@ -290,7 +336,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       GemmArgs g = make_args(ctx->dact[2], w3, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
       for (int kh = 0; kh < 3; ++kh)
         for (int kw = 0; kw < 3; ++kw) g.tapoff[0][kh * 3 + kw] = ((2 - kh) * 3 + (2 - kw)) * NT::C2 * NT::C3;
-      launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, s);
+      launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
     }
   }
   // (6) conv2 wgrad   [side stream, needs dact[1]]
@@ -303,7 +349,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     const int feats = NT::G2::FEATS;
     GemmArgs g = make_args(W.act[0], ctx->dact[1], slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
     g.slab_rows = feats + 1;
-    const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, side);
+    const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], side);
     wgrad_out(i_w2, feats, NT::C2, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C2;
   }
@@ -317,7 +363,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
         for (int kw = 0; kw < 2; ++kw)
           g.tapoff[par][kh * 2 + kw] = ((py + 2 * (1 - kh)) * 4 + (px + 2 * (1 - kw))) * NT::C1 * NT::C2;
     }
-    launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(g, 4, s);
+    launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(g, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
   }
   // (8) conv1 wgrad from the u8 frames
   {
@@ -325,7 +371,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     const int feats = 256;
     GemmArgs g = make_args(states, ctx->dact[0], slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
     g.slab_rows = feats + 1;
-    const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, s);
+    const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
     wgrad_out(i_w1, feats, NT::C1, slab, splits);
   }
   if (forked) {
@@ -386,4 +432,22 @@ int64_t wslab_floats_needed(int arch) {
 }
 int fc_splits_max() { return FC_SPLITS_MAX; }
 
+}  // namespace paac
+
+namespace paac {
+// Launch tuning measured on MI355X with tools/tune_gemm.py on the benchmark shapes (Nature, 32 envs x t_max 5:
+// batch 32 acting, 160 training; profiles/r01_tune_gemm.txt).  The sweep is flat -- the size heuristics are within
+// 1 us of the best everywhere except the entries below; anything else (other archs, larger batches) keeps the
+// heuristics.
+void default_tuning(paac_ctx* c) {
+  if (c->cfg.arch != PAAC_ARCH_NATURE || c->max_batch > 512) return;
+  c->tune[OP_CONV1_FWD][0] = Tune{2, 0, -1};
+  c->tune[OP_CONV1_FWD][1] = Tune{4, 0, -1};
+  c->tune[OP_CONV2_FWD][1] = Tune{4, 0, -1};
+  c->tune[OP_FC_FWD][1] = Tune{3, 6, -1};
+  c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
+  c->tune[OP_CONV3_WGRAD][1] = Tune{3, 48, 2};
+  c->tune[OP_CONV2_WGRAD][1] = Tune{3, 32, 2};
+  c->tune[OP_CONV1_WGRAD][1] = Tune{2, 64, 2};
+}
 }  // namespace paac

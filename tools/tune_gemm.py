@@ -1,0 +1,113 @@
+"""Coordinate-descent sweep of the GEMM launch configurations on the benchmark shapes (MI355X).
+Times the replayed forward (acting batch) and forward+backward (training batch) hipGraphs while changing one
+op's (cfg, ksplit, xcd) at a time through paac_debug_set_tuning; prints the best table as C++ for
+csrc/net.hip:default_tuning and as JSON (gpurun_out/tune.json)."""
+import ctypes, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from paac_amd import hip_ops, _lib
+
+ARCH = int(os.environ.get("TUNE_ARCH", "1"))
+A = int(os.environ.get("TUNE_A", "4"))
+N = int(os.environ.get("TUNE_N", "32"))
+T = int(os.environ.get("TUNE_T", "5"))
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+ctx = hip_ops.Context(ARCH, A, max_batch=N * T)
+P = torch.randn(ctx.layout["total"], device=dev) * 0.02
+S = torch.randint(0, 255, (N * T, 84, 84, 4), dtype=torch.uint8, device=dev)
+probs = torch.zeros(N, A, device=dev); vals = torch.zeros(N, device=dev)
+grad = torch.zeros(ctx.layout["total"], device=dev)
+acts = torch.zeros(N * T, dtype=torch.int32, device=dev)
+yy = torch.randn(N * T, device=dev); aa = torch.randn(N * T, device=dev)
+stream = torch.cuda.Stream()
+OPS = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgrad", "conv3_wgrad", "conv3_dgrad",
+       "conv2_wgrad", "conv2_dgrad", "conv1_wgrad"]
+if ARCH == 0:
+    OPS_ACTIVE = [0, 1, 3, 4, 5, 8, 9, 10]
+else:
+    OPS_ACTIVE = list(range(11))
+
+
+def set_tune(op, cls, cfg, ks, xcd):
+    _lib.check(lib.paac_debug_set_tuning(ctx.handle, op, cls, cfg, ks, xcd), "set_tuning")
+
+
+def time_graph(fn, reps=40):
+    with torch.cuda.stream(stream):
+        g = hip_ops.Graph(); g.begin(); fn(); g.end()
+        for _ in range(5):
+            g.launch()
+        stream.synchronize()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.launch()
+            stream.synchronize()
+            best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+        g.close()
+    return best
+
+
+def fwd_act():
+    ctx.forward(P, S[:N], probs=probs, values=vals)
+
+
+def train():
+    ctx.loss_backward(P, S, acts, yy, aa, 0.02, grad)
+
+
+def candidates(op, cls):
+    fam = "fwd" if op <= 3 else ("dgrad" if op in (5, 7, 9) else "wgrad")
+    out = []
+    if fam == "fwd" and op != 3:
+        out = [(c, 0, -1) for c in range(8)]
+    elif op == 3:
+        for c in range(8):
+            for ks in (1, 2, 3, 4, 6, 8):
+                out.append((c, ks, -1))
+                if ks == 8:
+                    out.append((c, ks, 2))
+    elif fam == "dgrad":
+        out = [(c, 0, x) for c in range(7) for x in (-1, 0, 1)]
+    elif op == 4:
+        out = [(c, 1, x) for c in range(6) for x in (-1, 0, 1)]
+    else:
+        cfgs = [0, 1, 2, 3] if op == 10 else range(6)
+        for c in cfgs:
+            for ks in (8, 16, 24, 32, 48, 64):
+                out.append((c, ks, -1)); out.append((c, ks, 2))
+    return out
+
+
+best = {}
+for cls, fn, label in ((0, fwd_act, "act B=%d" % N), (1, train, "train B=%d" % (N * T))):
+    if cls == 1 and N * T <= 64:
+        continue
+    base = time_graph(fn)
+    print("%s: heuristic graph %.1f us" % (label, base), flush=True)
+    ops = [o for o in OPS_ACTIVE if (o <= 3 or cls == 1)]
+    for rnd in range(2):
+        for op in ops:
+            cur = best.get((op, cls), (-1, 0, -1))
+            results = []
+            for cand in candidates(op, cls):
+                set_tune(op, cls, *cand)
+                results.append((time_graph(fn, reps=25), cand))
+            set_tune(op, cls, *cur)
+            ref = time_graph(fn, reps=25)
+            results.sort()
+            t_best, c_best = results[0]
+            if t_best < ref - 0.3:
+                best[(op, cls)] = c_best
+                set_tune(op, cls, *c_best)
+            print("  round %d %-12s current %s %.1f us | best %s %.1f us | top3 %s" % (
+                rnd, OPS[op], cur, ref, c_best, t_best, [(c, round(t, 1)) for t, c in results[:3]]), flush=True)
+    print("%s: tuned graph %.1f us (was %.1f)" % (label, time_graph(fn), base), flush=True)
+
+print("\n// default_tuning table (op, class) -> {cfg, ksplit, xcd}")
+for (op, cls), (c, ks, x) in sorted(best.items()):
+    print("  c->tune[%d][%d] = Tune{%d, %d, %d};   // %s" % (op, cls, c, ks, x, OPS[op]))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump({"%s/%d" % (OPS[o], c): v for (o, c), v in best.items()}, open("gpurun_out/tune_%d_%d_%d.json" % (ARCH, N, T), "w"))
