@@ -165,6 +165,15 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
                     uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
                     void* finished, uint8_t* raw_scratch, paac_stream_t stream);
 
+/* paac_sample_mt + paac_synth_step (path A) in ONE launch: workgroup 0 samples (numpy-parity MT19937 stream) and does
+ * the per-env bookkeeping while the other workgroups shift the observation stacks.  Limit: N*(A-1) <= 1024. */
+#define PAAC_FUSED_SAMPLE_MAX_DRAWS 1024
+int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
+                              uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
+                              uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, float* rewards_out,
+                              float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
+                              paac_stream_t stream);
+
 /* hipGraph helpers: capture every launch issued on `stream` between begin/end, replay with launch. */
 int paac_graph_begin(paac_stream_t stream);
 int paac_graph_end(paac_stream_t stream, paac_graph** out);

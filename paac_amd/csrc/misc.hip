@@ -120,11 +120,12 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
 // LDSPATH (N*(A-1) <= 1024): the three work arrays live in LDS instead of the global scratch.
 constexpr int MT_LDS_D = 1024;
 constexpr int MT_LDS_BLK = 5;   // 624 + 2*1024 u32 <= 5*624
+constexpr int MT_TAB_MAX = 16384;
 template <bool LDSPATH>
-__global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict__ probs, int N, int A,
-                                                        uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
-                                                        double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
-                                                        int32_t* __restrict__ actions) {
+__device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, int N, int A,
+                                               uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
+                                               double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
+                                               int32_t* __restrict__ actions, int32_t* act_lds) {
   __shared__ double pj_s[LDSPATH ? MT_LDS_D : 1];
   __shared__ double u_s[LDSPATH ? MT_LDS_D : 1];
   __shared__ uint32_t blocks_s[LDSPATH ? MT_LDS_BLK * 624 : 1];
@@ -134,20 +135,48 @@ __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict_
   const int tid = threadIdx.x;
   const int J = A - 1;
   const int D = N * J;
-  const uint32_t pos = mt_state[624];
+  __shared__ float probs_s[LDSPATH ? 2 * MT_LDS_D : 1];   // N*A = D*A/(A-1) <= 2*D floats
+  __shared__ uint32_t pos_s;
+  uint32_t pos;
+  if constexpr (LDSPATH) {
+    // ONE memory round trip: the 625 state words and the N*A probabilities are all requested before anything
+    // is consumed (unrolled, clamped indices), then parked in LDS.
+    uint32_t stw[3];
+    float prw[8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) stw[k] = mt_state[min(tid + k * 256, 624)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) prw[k] = probs[min(tid + k * 256, N * A - 1)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < 624) blocks[idx] = stw[k];
+      if (idx == 624) pos_s = stw[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (tid + k * 256 < N * A) probs_s[tid + k * 256] = prw[k];
+    __syncthreads();
+    pos = pos_s;
+  } else {
+    pos = mt_state[624];
+  }
+  const float* pr = LDSPATH ? probs_s : probs;
   const int nblk = (int)((pos + 2u * (uint32_t)D) / 624u) + 1;
   // phase 1: per-env conditional probabilities p_j / remaining_j (sequential fp64 subtraction order)
   for (int e = tid; e < N; e += 256) {
     double remaining = 1.0;
     for (int j = 0; j < J; ++j) {
-      const float p32 = probs[(long)e * A + j] - 5.9604644775390625e-08f;  // float32 arithmetic, paac.py:42
+      const float p32 = pr[(long)e * A + j] - 5.9604644775390625e-08f;  // float32 arithmetic, paac.py:42
       const double p = (double)p32;
       pj_buf[(long)e * J + j] = p / remaining;
       remaining -= p;
     }
   }
   // phase 2: successive MT19937 state blocks
-  for (int i = tid; i < 624; i += 256) blocks[i] = mt_state[i];
+  if constexpr (!LDSPATH) {
+    for (int i = tid; i < 624; i += 256) blocks[i] = mt_state[i];
+  }
   __syncthreads();
   for (int b = 1; b < nblk; ++b) {
     const uint32_t* o = blocks + (long)(b - 1) * 624;
@@ -169,11 +198,65 @@ __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict_
     u_buf[d] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
   }
   __syncthreads();
-  // phase 4: one wavefront walks the envs in index order; lane j owns category j
+  // phase 4a (fast path): when every conditional probability is non-zero the stream offset after env e is
+  // o + min(jh+1, J) with jh = first category hit when env e starts drawing at offset o.  jh is tabulated for
+  // every reachable (e, o) in parallel (o <= e*J), then one lane chases the table: N dependent LDS byte reads
+  // instead of N ballot/popcount/compare rounds.
+  __shared__ unsigned char jh_tab[LDSPATH ? MT_TAB_MAX : 1];
+  __shared__ int any_zero;
+  bool chased = false;
+  if constexpr (LDSPATH) {
+    const long tab_entries = (long)N + (long)J * N * (N - 1) / 2;
+    if (tab_entries <= MT_TAB_MAX && N <= 256) {
+      if (tid == 0) any_zero = 0;
+      __syncthreads();
+      for (int d = tid; d < D; d += 256)
+        if (pj_buf[d] == 0.0) any_zero = 1;
+      __syncthreads();
+      if (!any_zero) {
+        const int tpe = 256 / N;                       // threads per env
+        const int e = tid / tpe, k = tid - e * tpe;
+        if (e < N) {
+          const int base = e + J * e * (e - 1) / 2;    // sum_{e' < e} (e' J + 1)
+          for (int o = k; o <= e * J; o += tpe) {
+            int jh = J;
+            for (int j = J - 1; j >= 0; --j) {
+              const double pj = pj_buf[e * J + j];
+              const double U = u_buf[o + j < D ? o + j : D - 1];
+              bool hit;
+              if (pj <= 0.5) {
+                hit = U > 1.0 - pj;
+              } else {
+                const double q = 1.0 - pj;
+                hit = !(U > 1.0 - q);
+              }
+              if (hit) jh = j;
+            }
+            jh_tab[base + o] = (unsigned char)jh;
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int o = 0;
+          for (int e = 0; e < N; ++e) {
+            const int jh = jh_tab[e + J * e * (e - 1) / 2 + o];
+            actions[e] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
+            if (act_lds) act_lds[e] = jh;
+            o += (jh + 1 < J) ? jh + 1 : J;
+          }
+          jh_tab[0] = 0;
+          any_zero = o;                                 // reuse as the consumed-draw count
+        }
+        __syncthreads();
+        chased = true;
+      }
+    }
+  }
+  // phase 4b: one wavefront walks the envs in index order; lane j owns category j
   if (tid < 64) {
     const int lane = tid;
-    int o = 0;
-    for (int e = 0; e < N; ++e) {
+    int o = chased ? any_zero : 0;
+    for (int e = chased ? N : 0; e < N; ++e) {
       const bool mine = lane < J;
       const double pj = mine ? pj_buf[(long)e * J + lane] : 0.0;
       const bool nzl = mine && (pj != 0.0);
@@ -198,7 +281,10 @@ __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict_
         act = A - 1;
         used = __popcll(nz);
       }
-      if (lane == 0) actions[e] = act;
+      if (lane == 0) {
+        actions[e] = act;
+        if (act_lds) act_lds[e] = act;
+      }
       o += used;
     }
     // write back the stream position in numpy's convention (pos in [0,624], regenerate lazily)
@@ -213,6 +299,14 @@ __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict_
       for (int i = lane; i < 624; i += 64) mt_state[i] = blocks[(long)fb * 624 + i];
     if (lane == 0) mt_state[624] = np;
   }
+}
+
+template <bool LDSPATH>
+__global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict__ probs, int N, int A,
+                                                        uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
+                                                        double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
+                                                        int32_t* __restrict__ actions) {
+  sample_mt_body<LDSPATH>(probs, N, A, mt_state, pj_g, u_g, blocks_g, actions, nullptr);
 }
 
 // =============================================================================================
@@ -378,6 +472,46 @@ __global__ __launch_bounds__(256) void synth_step_a_kernel(uint64_t seed, uint32
     const uint32_t outv = (old >> 8) | (nv << 24);
     stack_out[pix] = outv;
     if (stack_out2) stack_out2[pix] = outv;
+  }
+}
+
+// Path A with the numpy-parity sampler folded in: workgroup 0 runs the (inherently serial) MT19937 sampler and then
+// the per-env bookkeeping, the other N*7 workgroups shift the observation stacks meanwhile -- the new frame and the
+// terminal flag of the synthetic environments do not depend on the action, only reward bookkeeping does.  One launch
+// per time step instead of two.
+__global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __restrict__ probs, int A,
+                                                              uint32_t* __restrict__ mt_state,
+                                                              int32_t* __restrict__ actions, uint64_t seed,
+                                                              uint32_t env_offset, int N, uint32_t thresh,
+                                                              const uint64_t* __restrict__ step_base, uint64_t step_off,
+                                                              const uint32_t* __restrict__ stack_in,
+                                                              uint32_t* __restrict__ stack_out, float* rewards_out,
+                                                              float* masks_out, float* ep_reward, int32_t* ep_len,
+                                                              FinishedRing* fin) {
+  const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
+  if (blockIdx.x == 0) {
+    __shared__ int32_t act_s[MT_LDS_D];
+    sample_mt_body<true>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);
+    __syncthreads();
+    for (int e = threadIdx.x; e < N; e += 256) {
+      const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
+      synth_bookkeep(key, e, act_s, thresh, rewards_out, masks_out, ep_reward, ep_len, fin);
+    }
+    return;
+  }
+  const int e = (blockIdx.x - 1) / PRE_BANDS;
+  const int band = (blockIdx.x - 1) % PRE_BANDS;
+  const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
+  const bool reset = lowbias32(key ^ 0x3C6EF372u) < thresh;
+  constexpr int PIX_PER_BAND = OBS_PIX / PRE_BANDS;  // 1008
+  for (int i = threadIdx.x; i < PIX_PER_BAND; i += 256) {
+    const int p = band * PIX_PER_BAND + i;
+    const int y = p / 84, x = p - y * 84;
+    const uint32_t w = synth_word(key, (uint32_t)(y * 21 + (x >> 2)));
+    const uint32_t nv = (w >> (8 * (x & 3))) & 255u;
+    const long pix = (long)e * OBS_PIX + p;
+    const uint32_t old = reset ? 0u : stack_in[pix];
+    stack_out[pix] = (old >> 8) | (nv << 24);
   }
 }
 
@@ -618,6 +752,24 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
                        (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)stack_out2, (const uint8_t*)nullptr,
                        (const uint8_t*)nullptr, (const float*)masks_out);
   }
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
+                              uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
+                              uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, float* rewards_out,
+                              float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
+                              paac_stream_t stream) {
+  PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
+  PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
+               "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D);
+  PAAC_REQUIRE(probs && mt_state && actions && stack_in && stack_out && rewards_out && masks_out && ep_reward && ep_len,
+               "paac_sample_mt_synth_step: null argument");
+  hipLaunchKernelGGL(synth_step_a_mt_kernel, dim3(1 + N * PRE_BANDS), dim3(256), 0, (hipStream_t)stream, probs, A,
+                     mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset,
+                     (const uint32_t*)stack_in, (uint32_t*)stack_out, rewards_out, masks_out, ep_reward, ep_len,
+                     (FinishedRing*)finished);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

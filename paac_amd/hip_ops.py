@@ -278,6 +278,30 @@ def synth_step(seed, env_offset, actions, terminal_threshold, step_base_dev, ste
                                            _stream()), "paac_synth_step")
 
 
+FUSED_SAMPLE_MAX_DRAWS = 1024
+
+
+def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_threshold, step_base_dev, step_offset,
+                         stack_in, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None):
+    N, A = probs.shape
+    if N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
+        raise ValueError("fused sampler+env step supports N*(A-1) <= %d" % FUSED_SAMPLE_MAX_DRAWS)
+    for nm, t in (("stack_in", stack_in), ("stack_out", stack_out)):
+        if tuple(t.shape) != (N,) + OBS_SHAPE:
+            raise ValueError("%s must be [%d,84,84,4], got %s" % (nm, N, tuple(t.shape)))
+    if finished is not None and finished.numel() * finished.element_size() < FINISHED_RING_BYTES:
+        raise ValueError("finished ring too small")
+    _lib.check(_lib.load().paac_sample_mt_synth_step(
+        _ptr(probs, torch.float32, N * A, "probs"), A, _ptr(mt_state, torch.int32, 625, "mt_state"),
+        _ptr(actions, torch.int32, N, "actions"), int(seed), int(env_offset), N, int(terminal_threshold),
+        _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
+        _ptr(stack_in, torch.uint8, N * 28224, "stack_in"), _ptr(stack_out, torch.uint8, N * 28224, "stack_out"),
+        _ptr(rewards_out, torch.float32, N, "rewards_out"), _ptr(masks_out, torch.float32, N, "masks_out"),
+        _ptr(ep_reward, torch.float32, N, "ep_reward"), _ptr(ep_len, torch.int32, N, "ep_len"),
+        ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),
+        "paac_sample_mt_synth_step")
+
+
 class Graph(object):
     """hipGraph captured from the launches issued on torch's current stream between begin() and end()."""
 

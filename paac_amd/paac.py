@@ -82,6 +82,14 @@ class DeviceRollout(object):
         params = L.network.params
         st = [self.states[self._slot(parity, t)] for t in range(T + 1)]
         for t in range(T):
+            if self.sampler == "numpy" and self.raw is None and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS:
+                # numpy-parity sampler and env step in one launch (the frame shift does not need the action)
+                L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
+                hip_ops.sample_mt_synth_step(self.probs, self.mt_state, self.actions[t], self.env_spec["seed"],
+                                             self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
+                                             st[t], st[t + 1], self.rewards[t], self.masks[t], self.ep_reward,
+                                             self.ep_len, self.finished)
+                continue
             if self.sampler == "numpy":
                 L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
                 hip_ops.sample_mt(self.probs, self.mt_state, self.mt_scratch, self.actions[t])
