@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
   constexpr int T = TM * TN;
   constexpr int LDS_F4 = (WK > 1) ? (NWM * NWN * WK * T * 64) : 1;
   __shared__ f32x4 red[LDS_F4 + (BIASROW ? NWN * WK * 16 : 0)];
+  __shared__ __attribute__((aligned(16))) float epi[(BP == FRAG_K) ? NWM * NWN * WK * 16 * (TN * 16 + 4) : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -347,12 +348,12 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
         c[tn] = acc[tm][tn];
       }
     }
+    if constexpr (BP == FRAG_MN) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      // global row of D element (tile tm, row 4q+r)
-      const int m = (AP == FRAG_K) ? (m0 + tm * 16 + 4 * q + r) : (m0 + TM * (4 * q + r) + tm);
-      if (m >= p.M) continue;
-      if constexpr (BP == FRAG_MN) {
+      for (int r = 0; r < 4; ++r) {
+        // global row of D element (tile tm, row 4q+r)
+        const int m = (AP == FRAG_K) ? (m0 + tm * 16 + 4 * q + r) : (m0 + TM * (4 * q + r) + tm);
+        if (m >= p.M) continue;
         const int n = n0 + TN * li;
         if (n >= p.N) continue;
         f32x4 v;
@@ -367,24 +368,46 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
           static_assert(BP != FRAG_MN || EPI == EPI_BIAS_RELU || EPI == EPI_SLAB, "FRAG_MN B epilogues");
           storev<TN>(p.out + ((long)z * p.slab_rows + m) * p.ldo + n, v);
         }
-      } else {
-        long orow = m;
-        if constexpr (EPI == EPI_MASK_PARITY) {
-          const int b = m / G::OPIX;
-          const int rem = m - b * G::OPIX;
-          const int a = rem / G::OW;
-          const int cc = rem - a * G::OW;
-          orow = ((long)b * (2 * G::OH) + 2 * a + (z >> 1)) * (2 * G::OW) + 2 * cc + (z & 1);
-        }
+      }
+    } else {
+      // dgrad: the D layout has the output column on the lane; transpose the unit through a wave-private LDS tile
+      // so that each lane owns 4 consecutive columns of a row: one float4 mask load + one float4 store per lane
+      // and pass instead of 4*TN scalar pairs.
+      static_assert(BP == FRAG_MN || AP == FRAG_K, "dgrad epilogue assumes FRAG_K A");
+      constexpr int EW = TN * 16 + 4;
+      float* et = epi + wave * (16 * EW);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int n = n0 + tn * 16 + li;
-          if (n < p.N) {
-            const float act = p.aux[orow * p.ldo + n];
-            p.out[orow * p.ldo + n] = act > 0.f ? c[tn][r] : 0.f;
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) et[(4 * q + r) * EW + tn * 16 + li] = c[tn][r];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int F4_PER_ROW = TN * 4;
+      constexpr int ROWS_PER_PASS = 64 / F4_PER_ROW;
+#pragma unroll
+      for (int pass = 0; pass < 16 / ROWS_PER_PASS; ++pass) {
+        const int row = pass * ROWS_PER_PASS + lane / F4_PER_ROW;
+        const int c4 = (lane % F4_PER_ROW) * 4;
+        const int m = m0 + tm * 16 + row;
+        const int n = n0 + c4;
+        if (m < p.M && n < p.N) {
+          long orow = m;
+          if constexpr (EPI == EPI_MASK_PARITY) {
+            const int b = m / G::OPIX;
+            const int rem = m - b * G::OPIX;
+            const int a = rem / G::OW;
+            const int cc = rem - a * G::OW;
+            orow = ((long)b * (2 * G::OH) + 2 * a + (z >> 1)) * (2 * G::OW) + 2 * cc + (z & 1);
           }
+          const f32x4 act = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + n);
+          f32x4 v = *reinterpret_cast<const f32x4*>(et + row * EW + c4);
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) v[e4] = act[e4] > 0.f ? v[e4] : 0.f;
+          *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n) = v;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 
