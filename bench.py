@@ -12,9 +12,10 @@ slowest rank's wall time (weak scaling: 32 envs per GPU).  Workload at N=1 = BAS
 (Breakout action set, Nature net, 32 envs, t_max=5).
 
 Extra objects on the JSON line:
-  roofline     -- the kernel family with the largest share of the cycle, timed with HIP events on the launch
-                  stream in a second, eager (graph-free) pass over the same K steps; achieved = algorithmic
-                  FLOPs (or bytes) per launch / average launch duration.
+  roofline     -- the kernel family with the largest share of the cycle, timed with HIP events attached to the
+                  kernel dispatches (hipExtLaunchKernelGGL start/stop events on the launch stream) in a second,
+                  eager (graph-free) pass over the same K steps; achieved = algorithmic FLOPs (or bytes) per
+                  launch / average launch duration; traffic = PMC bytes per launch from profiles/ (separate passes).
   cpu_baseline -- oracle/cpu_learner.py (torch-CPU port of the reference loop; the reference's TF path cannot
                   run here) on a bounded sample, rank 0, N=1 only.
 """
@@ -173,14 +174,29 @@ def main():
                                 unit="TFLOP/s" if kind == "flop" else "GB/s"))
         kernels.sort(key=lambda k: -k["us_per_step"])
         dom = kernels[0]
+        # HBM-side traffic of the dominant kernel from the committed PMC passes (collected separately, as rocprofv3
+        # requires; profiles/*_traffic_by_family.json) when they were taken on this workload
+        traffic = None
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_by_family.json")))
+            if cand:
+                tj = json.load(open(cand[-1]))
+                key = "%s[batch=%d]" % (dom["kernel"], dom["batch"])
+                if tj.get("workload", "").split(", sampler")[0] == ("%s action set (A=%d), %s net, %d envs per GPU x 1 GPU, t_max=%d, %s" % (
+                        a.game, A, a.arch, N, T, "raw 210x160 frame pairs + GPU max/resize/stack" if a.raw_frames else
+                        "synthetic 84x84x4 u8 frames generated on device")):
+                    traffic = tj["bytes_per_launch"].get(key)
+        except Exception:
+            traffic = None
         if dom["unit"] == "TFLOP/s":
             roofline = dict(bound="mfma", kernel="%s[batch=%d]" % (dom["kernel"], dom["batch"]), achieved=dom["achieved"],
                             peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                            avg_launch_us=dom["avg_us"], traffic=None)
+                            avg_launch_us=dom["avg_us"], traffic=traffic)
         else:
             roofline = dict(bound="hbm", kernel="%s[batch=%d]" % (dom["kernel"], dom["batch"]), achieved=dom["achieved"],
                             peak=PEAK_HBM_GBS, unit="GB/s", frac=round(dom["achieved"] / PEAK_HBM_GBS, 4),
-                            avg_launch_us=dom["avg_us"], traffic=None)
+                            avg_launch_us=dom["avg_us"], traffic=traffic)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -9,6 +9,7 @@
 namespace paac {
 
 static thread_local char g_err[512] = "";
+thread_local ProfEvents g_prof = {nullptr, nullptr};
 
 void set_error(const char* fmt, ...) {
   va_list ap;

@@ -1,6 +1,7 @@
 // Internal definitions shared by the kernel translation units of libpaac_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -108,23 +109,43 @@ struct paac_ctx {
 
 namespace paac {
 
-// RAII-less helpers used by the launchers: record start/stop events when profiling is on.
+// Timing hooks: while a ProfScope is alive, launch_k() attaches its start/stop events to the kernel dispatch itself
+// (hipExtLaunchKernelGGL: the events carry the dispatch's own begin/end timestamps, like rocprofv3's kernel trace),
+// so the elapsed time is the kernel's GPU duration without marker-packet overhead.  A scope with several launches
+// (first_only / last_only) puts the start on the first and the stop on the last.
+struct ProfEvents {
+  hipEvent_t start, stop;
+};
+extern thread_local ProfEvents g_prof;
+
 struct ProfScope {
   paac_ctx* ctx;
-  hipStream_t s;
   int idx;
-  ProfScope(paac_ctx* c, int family, int batch, hipStream_t stream) : ctx(c), s(stream), idx(-1) {
+  ProfScope(paac_ctx* c, int family, int batch, hipStream_t) : ctx(c), idx(-1) {
     if (c && c->prof_on && c->ev_count < paac_ctx::PROF_MAX_EVENTS) {
       idx = c->ev_count++;
       c->ev_family[idx] = family;
       c->ev_batch[idx] = batch;
-      (void)hipEventRecord(c->ev_start[idx], s);
+      g_prof.start = c->ev_start[idx];
+      g_prof.stop = c->ev_stop[idx];
     }
   }
   ~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(ctx->ev_stop[idx], s);
+    g_prof.start = nullptr;
+    g_prof.stop = nullptr;
   }
 };
+
+enum { PROF_WHOLE = 0, PROF_FIRST = 1, PROF_LAST = 2, PROF_NONE = 3 };
+template <class K, class... Args>
+inline void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, int part, Args... args) {
+  hipEvent_t st = (part == PROF_WHOLE || part == PROF_FIRST) ? g_prof.start : nullptr;
+  hipEvent_t sp = (part == PROF_WHOLE || part == PROF_LAST) ? g_prof.stop : nullptr;
+  if (st || sp)
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, s, st, sp, 0, args...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+}
 
 // launchers implemented in the kernel translation units
 int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,

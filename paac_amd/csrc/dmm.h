@@ -456,8 +456,8 @@ inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, int xcd_dim, hipStrea
   if (xcd_dim == 0) blocks = (long)((a.MT + 7) / 8) * 8 * a.NT * a.Z;
   if (xcd_dim == 1) blocks = (long)((a.NT + 7) / 8) * 8 * a.MT * a.Z;
   if (xcd_dim == 2) blocks = (long)((a.Z + 7) / 8) * 8 * a.MT * a.NT;
-  hipLaunchKernelGGL((dmm_kernel<G, U8, AP, BP, TM, TN, NWM, NWN, WK, BCO, EPI, BIASROW, PF>), dim3((unsigned)blocks),
-                     dim3(64 * NWM * NWN * WK), 0, s, a);
+  launch_k(dmm_kernel<G, U8, AP, BP, TM, TN, NWM, NWN, WK, BCO, EPI, BIASROW, PF>, dim3((unsigned)blocks),
+           dim3(64 * NWM * NWN * WK), s, PROF_WHOLE, a);
 }
 
 }  // namespace paac

@@ -348,17 +348,17 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 // Dispatch on the action-count bucket.
 template <int H, class... Args>
 inline void launch_heads_fwd(int A, dim3 grid, hipStream_t s, Args... args) {
-  if (A <= 4) hipLaunchKernelGGL((heads_fwd_kernel<H, 4>), grid, dim3(256), 0, s, args...);
-  else if (A <= 8) hipLaunchKernelGGL((heads_fwd_kernel<H, 8>), grid, dim3(256), 0, s, args...);
-  else if (A <= 20) hipLaunchKernelGGL((heads_fwd_kernel<H, 20>), grid, dim3(256), 0, s, args...);
-  else hipLaunchKernelGGL((heads_fwd_kernel<H, 32>), grid, dim3(256), 0, s, args...);
+  if (A <= 4) launch_k(heads_fwd_kernel<H, 4>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else if (A <= 8) launch_k(heads_fwd_kernel<H, 8>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else if (A <= 20) launch_k(heads_fwd_kernel<H, 20>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else launch_k(heads_fwd_kernel<H, 32>, grid, dim3(256), s, PROF_WHOLE, args...);
 }
 template <int H, class... Args>
 inline void launch_heads_bwd(int A, dim3 grid, hipStream_t s, Args... args) {
-  if (A <= 4) hipLaunchKernelGGL((heads_bwd_kernel<H, 4>), grid, dim3(256), 0, s, args...);
-  else if (A <= 8) hipLaunchKernelGGL((heads_bwd_kernel<H, 8>), grid, dim3(256), 0, s, args...);
-  else if (A <= 20) hipLaunchKernelGGL((heads_bwd_kernel<H, 20>), grid, dim3(256), 0, s, args...);
-  else hipLaunchKernelGGL((heads_bwd_kernel<H, 32>), grid, dim3(256), 0, s, args...);
+  if (A <= 4) launch_k(heads_bwd_kernel<H, 4>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else if (A <= 8) launch_k(heads_bwd_kernel<H, 8>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else if (A <= 20) launch_k(heads_bwd_kernel<H, 20>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else launch_k(heads_bwd_kernel<H, 32>, grid, dim3(256), s, PROF_WHOLE, args...);
 }
 
 }  // namespace paac

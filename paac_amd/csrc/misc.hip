@@ -784,9 +784,9 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(ctx, F_CLIP_RMSPROP, (int)(n / 4), s);
   const long n4 = n / 4;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grad, n4, grad_scale, ctx->partials);
-  hipLaunchKernelGGL(rmsprop_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, params, grad, ms, mom, n4, lr_dev, decay,
-                     momentum, eps, clip_norm, clip_mode, grad_scale, ctx->partials, gnorm_out);
+  launch_k(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), s, PROF_FIRST, grad, n4, grad_scale, ctx->partials);
+  launch_k(rmsprop_kernel, dim3((n4 + 255) / 256), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev, decay,
+           momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

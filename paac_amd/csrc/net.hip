@@ -382,7 +382,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     ProfScope ps(ctx, F_GRAD_FINALIZE, batch, s);
     int maxcount = 0;
     for (int i = 0; i < fin.nseg; ++i) maxcount = fin.seg[i].count > maxcount ? fin.seg[i].count : maxcount;
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3((maxcount / 4 + 255) / 256, fin.nseg), dim3(256), 0, s, fin);
+    launch_k(grad_finalize_kernel, dim3((maxcount / 4 + 255) / 256, fin.nseg), dim3(256), s, PROF_WHOLE, fin);
   }
   return 0;
 }

@@ -1,0 +1,80 @@
+"""Condense gpurun_out/<run>/ (rocprofv3 --stats, --pmc passes, bench JSON, tuner log) into profiles/<tag>_*."""
+import collections, csv, glob, json, os, re, shutil, sys
+src, tag = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(n):
+    n = re.sub(r'paac::', '', n)
+    m = re.match(r'void dmm_kernel<Geom<([0-9, ]+)>, (true|false), (\d), (\d), (\d), (\d), (\d), (\d), (\d), (\d+), (\d), (true|false), (\d)>', n)
+    if m:
+        return 'dmm<G%s u8=%s ap%s bp%s T%sx%s W%s,%s,%s epi%s bias=%s pf%s>' % (
+            m.group(1).replace(' ', ''), m.group(2)[0], m.group(3), m.group(4), m.group(5), m.group(6), m.group(7), m.group(8),
+            m.group(9), m.group(11), m.group(12)[0], m.group(13))
+    return n.split('(')[0][:70]
+
+# 1. rocprofv3 --kernel-trace --stats summary (verbatim csv) + one-cycle timeline
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
+trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Start_Timestamp']))
+marks = [i for i, r in enumerate(rows) if 'rmsprop_kernel' in r['Kernel_Name']]
+k = len(marks) // 3          # a steady-state cycle of the hipGraph phase (the tail of the trace is the eager, event-bracketed pass)
+i0, i1 = marks[k] + 1, marks[k + 1] + 1
+t0 = int(rows[i0]['Start_Timestamp'])
+with open("profiles/%s_cycle_timeline.txt" % tag, "w") as f:
+    f.write("# one steady-state PAAC cycle (bench.py under rocprofv3 --kernel-trace): start_us end_us dur_us workgroups x threads kernel\n")
+    for r in rows[i0:i1]:
+        s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
+        wg = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) // int(r['Workgroup_Size_X'])
+        f.write("%8.1f %8.1f %6.1f  %6d x %3d  %s\n" % (s / 1000, e / 1000, (e - s) / 1000, wg, int(r['Workgroup_Size_X']), short(r['Kernel_Name'])))
+    f.write("# cycle wall %.1f us, %d kernels\n" % ((int(rows[i1]['Start_Timestamp']) - t0) / 1000, i1 - i0))
+
+# 2. PMC traffic per kernel (separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B)
+def pmc(name, counter):
+    f = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = (short(r['Kernel_Name']), r.get('Grid_Size', ''))
+        agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
+    return agg
+fe, wr = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+traffic = {}
+with open("profiles/%s_pmc_traffic.csv" % tag, "w") as f:
+    f.write("kernel,grid_size,launches,FETCH_SIZE_KB_raw_per_launch,fetch_bytes_corrected_x2,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch\n")
+    for k in sorted(fe, key=lambda k: -fe[k][0]):
+        fk = fe[k][0] / fe[k][1]
+        wk = wr.get(k, [0, 1])[0] / max(1, wr.get(k, [0, 1])[1])
+        tot = (2 * fk + wk) * 1024
+        traffic["%s|%s" % k] = tot
+        f.write("\"%s\",%s,%d,%.1f,%.0f,%.1f,%.0f\n" % (k[0], k[1], fe[k][1], fk, 2 * fk * 1024, wk, tot))
+json.dump(traffic, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
+
+# per kernel-family table in bench.py's naming ("family[batch=B]"): the family is read off the template arguments
+# (geometry + fragment pattern), the batch off the traffic (the smaller launch of a family is the acting batch)
+PATTERNS = [("conv1_fwd", "G84,84,4,20,20", "ap0"), ("conv1_wgrad", "G84,84,4,20,20", "ap1"),
+            ("conv2_fwd", "G20,20,", "ap0"), ("conv2_wgrad", "G20,20,", "ap1"),
+            ("conv3_fwd", "G9,9,64,7,7,1,0,0", "ap0"), ("conv3_wgrad", "G9,9,64,7,7,1,0,0", "ap1"),
+            ("fc_fwd", "G1,1,3136", "ap0"), ("fc_wgrad", "G1,1,3136", "ap1"), ("fc_dgrad", "G1,1,512", "ap0"),
+            ("conv3_dgrad", "G7,7,64,9,9", "ap0"), ("conv2_dgrad", "G9,9,64,10,10", "ap0")]
+meta = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+n_act, n_train = meta["config"]["envs_per_gpu"], meta["config"]["envs_per_gpu"] * meta["config"]["t_max"]
+fam = {}
+for name, gpat, ap in PATTERNS:
+    ks = sorted([k for k in fe if gpat in k[0] and (" %s " % ap) in k[0]], key=lambda k: traffic["%s|%s" % k])
+    batches = [n_act, n_train] if len(ks) == 2 else ([n_train] if "grad" in name else [n_act])
+    for k, b in zip(ks, batches):
+        fam["%s[batch=%d]" % (name, b)] = traffic["%s|%s" % k]
+json.dump({"workload": meta["config"]["workload"], "bytes_per_launch": fam,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                     "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B); average per launch"},
+          open("profiles/%s_traffic_by_family.json" % tag, "w"), indent=1)
+
+# 3. bench lines + tuner log
+for name in ("bench_default.json", "bench_philox.json", "tune_gemm.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, "profiles/%s_%s" % (tag, name))
+print(open("profiles/%s_cycle_timeline.txt" % tag).read()[-600:])
