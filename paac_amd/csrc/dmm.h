@@ -59,6 +59,7 @@ struct GemmArgs {
   // grid dimension (0 = M tiles, 1 = N tiles, 2 = z) whose index is tied to the XCD, so that all workgroups that
   // share the big operand slice of one index run on one XCD; -1 = plain (x fastest) order.
   int MT, NT, Z, xcd_dim;
+  unsigned a_bytes, b_bytes;   // extents of the A / B tensors (buffer-resource range check)
 #ifdef PAAC_DMM_STAMPS
   unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave
 #endif
@@ -87,6 +88,44 @@ __device__ __forceinline__ f32x4 load4(const void* base, long off) {
                    (float)v.w * kInputScale};
   } else {
     return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + off);
+  }
+}
+
+// Buffer-resource loads (SRSRC in SGPRs + 32-bit per-lane byte offset + scalar byte offset): no 64-bit address
+// arithmetic and no per-load predication in the K loop -- a lane whose row/column is out of range carries the
+// sentinel offset and the hardware range check returns zeros.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOob = 0x80000000u;   // >= num_records of any tensor here (< 2 GiB)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+template <bool U8>
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (U8) {
+    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    return (f32x4){(float)(v & 255u) * kInputScale, (float)((v >> 8) & 255u) * kInputScale,
+                   (float)((v >> 16) & 255u) * kInputScale, (float)(v >> 24) * kInputScale};
+  } else {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  }
+}
+
+// NOTE (ROCm 7.2 hipcc): __builtin_amdgcn_raw_buffer_load_b64 is lowered to a single buffer_load_dword (the
+// second dword is garbage), so 8-byte fragments go through a plain global load off the uniform base pointer
+// (global_load_dwordx2 with an SGPR base + 32-bit VGPR offset); out-of-range lanes are zeroed by a select.
+template <int V>
+__device__ __forceinline__ f32x4 bloadv(__amdgpu_buffer_rsrc_t r, const void* base, unsigned voff, unsigned soff) {
+  if constexpr (V == 4) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  } else if constexpr (V == 2) {
+    const bool ok = voff < kOob;
+    const float2 t = *reinterpret_cast<const float2*>(static_cast<const char*>(base) + (ok ? voff + soff : 0u));
+    return (f32x4){ok ? t.x : 0.f, ok ? t.y : 0.f, 0.f, 0.f};
+  } else {
+    return (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)), 0.f, 0.f, 0.f};
   }
 }
 
@@ -131,7 +170,7 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: scalar offsets below
   const int wk = wave % WK;
   const int wn = (wave / WK) % NWN;
   const int wm = wave / (WK * NWN);
@@ -177,10 +216,13 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
   DMM_STAMP(1);
 
   // ---- per-lane invariants ------------------------------------------------------------------------
-  // FRAG_K A: TM patch rows fixed for the whole loop
-  long a_base[(AP == FRAG_K) ? TM : 1];
+  constexpr unsigned ES = U8 ? 1u : 4u;   // bytes per A element
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+  // FRAG_K A: TM patch rows fixed for the whole loop -> one 32-bit byte offset per tile (sentinel when the row
+  // is out of range); the K group only moves a wave-uniform scalar offset.
+  unsigned a_voff[(AP == FRAG_K) ? TM : 1];
   int a_iy0[(AP == FRAG_K) ? TM : 1], a_ix0[(AP == FRAG_K) ? TM : 1];
-  bool a_ok[(AP == FRAG_K) ? TM : 1];
   // FRAG_MN A (wgrad): the lane's TM consecutive features are fixed, rows move
   int f_kh = 0, f_kwc = 0, f_kw = 0;
   bool f_ok = false;
@@ -188,15 +230,17 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       const int row = m0 + t * 16 + li;
-      a_ok[t] = row < p.M;
-      const int r = a_ok[t] ? row : 0;
+      const bool ok = row < p.M;
+      const int r = ok ? row : 0;
       const int b = r / G::OPIX;
       const int rem = r - b * G::OPIX;
       const int oy = rem / G::OW;
       const int ox = rem - oy * G::OW;
       a_iy0[t] = oy * G::S - G::PH;
       a_ix0[t] = ox * G::S - G::PW;
-      a_base[t] = ((long)(b * G::IH + a_iy0[t]) * G::IW + a_ix0[t]) * G::C + 4 * kq;
+      const int base = ((b * G::IH + a_iy0[t]) * G::IW + a_ix0[t]) * G::C + 4 * kq;   // elements; may be < 0 when padded
+      a_voff[t] = ok ? (unsigned)base * ES : kOob;
+      if constexpr (G::PADDED) a_iy0[t] = ok ? a_iy0[t] : -(1 << 20);   // padded path re-derives validity per group
     }
   } else {
     const int f = m0 + TM * li;
@@ -205,42 +249,47 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
     f_kwc = f - f_kh * G::KWC;
     f_kw = f_kwc / G::C;
   }
-  // FRAG_K B (dgrad): TN weight rows (output channels of the transposed conv) fixed
-  long b_base[(BP == FRAG_K) ? TN : 1];
-  bool b_ok[(BP == FRAG_K) ? TN : 1];
+  // FRAG_K B (dgrad): TN weight rows (input channels of the forward conv) fixed
+  unsigned b_voff[(BP == FRAG_K) ? TN : 4];
   if constexpr (BP == FRAG_K) {
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
       const int n = n0 + t * 16 + li;
-      b_ok[t] = n < p.N;
-      b_base[t] = (long)(b_ok[t] ? n : 0) * BCO + 4 * kq;
+      b_voff[t] = (n < p.N) ? (unsigned)(n * BCO + 4 * kq) * 4u : kOob;
     }
+  } else {
+    // FRAG_MN B: row 4*kq + s of the group, TN consecutive columns
+    const bool ok = n0 + TN * li < p.N;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b_voff[s] = ok ? (unsigned)((4 * kq + s) * p.ldb + n0 + TN * li) * 4u : kOob;
   }
-  const bool bn_ok = (BP == FRAG_MN) ? (n0 + TN * li < p.N) : true;
 
   // ---- fragment loads for K group `g` (k16 = 16 g) --------------------------------------------------
   f32x4 fa[RING][NA], fb[RING][NB];
   auto load_group = [&](int slot, int g) {
-    const int k16 = g * 16;
+    const int k16 = g * 16;   // wave-uniform
     if constexpr (AP == FRAG_K) {
-      const int kh = k16 / G::KWC;               // wave-uniform
+      const int kh = k16 / G::KWC;
       const int kwc = k16 - kh * G::KWC;
-      const long goff = (long)kh * (G::IW * G::C) + kwc;
+      const unsigned goff = (unsigned)(kh * (G::IW * G::C) + kwc) * ES;
+      if constexpr (!G::PADDED) {
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        bool ok = a_ok[t];
-        if constexpr (G::PADDED) {
+        for (int t = 0; t < TM; ++t) fa[slot][t] = bload4<U8>(rsA, a_voff[t], goff);
+      } else {
+        const int kw = kwc / G::C;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
           const int iy = a_iy0[t] + kh;
-          const int ix = a_ix0[t] + kwc / G::C;
-          ok = ok && (iy >= 0) && (iy < G::IH) && (ix >= 0) && (ix < G::IW);
+          const int ix = a_ix0[t] + kw;
+          const bool ok = (iy >= 0) && (iy < G::IH) && (ix >= 0) && (ix < G::IW);
+          fa[slot][t] = bload4<U8>(rsA, ok ? a_voff[t] + goff : kOob, 0);
         }
-        fa[slot][t] = ok ? load4<U8>(p.A, a_base[t] + goff) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int r = k16 + 4 * kq + s;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        unsigned off = kOob;
         if (f_ok && r < p.K) {
           const int b = r / G::OPIX;
           const int rem = r - b * G::OPIX;
@@ -250,31 +299,31 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
           const int ix0 = ox * G::S - G::PW;
           bool ok = true;
           if constexpr (G::PADDED) ok = (iy >= 0) && (iy < G::IH) && (ix0 + f_kw >= 0) && (ix0 + f_kw < G::IW);
-          if (ok) {
-            const long off = ((long)(b * G::IH + iy) * G::IW + ix0) * G::C + f_kwc;
-            if constexpr (U8) {
-              static_assert(!U8 || TM == 4, "u8 FRAG_MN loads are uchar4");
-              v = load4<true>(p.A, off);
-            } else {
-              v = loadv<TM>(static_cast<const float*>(p.A) + off);
-            }
-          }
+          if (ok) off = (unsigned)(((b * G::IH + iy) * G::IW + ix0) * G::C + f_kwc) * ES;
         }
-        fa[slot][s] = v;
+        if constexpr (U8) {
+          static_assert(!U8 || TM == 4, "u8 FRAG_MN loads are uchar4");
+          fa[slot][s] = bload4<true>(rsA, off, 0);
+        } else {
+          fa[slot][s] = bloadv<TM>(rsA, p.A, off, 0);
+        }
       }
     }
     if constexpr (BP == FRAG_K) {
-      const int tap = k16 / BCO;                 // wave-uniform
+      const int tap = k16 / BCO;
       const int co = k16 - tap * BCO;
-      const long goff = (long)p.tapoff[par][tap] + co;
+      const unsigned goff = (unsigned)(p.tapoff[par][tap] + co) * 4u;
 #pragma unroll
-      for (int t = 0; t < TN; ++t)
-        fb[slot][t] = b_ok[t] ? *reinterpret_cast<const f32x4*>(p.B + b_base[t] + goff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < TN; ++t) fb[slot][t] = bload4<false>(rsB, b_voff[t], goff);
     } else {
+      const unsigned goff = (unsigned)(k16 * p.ldb) * 4u;
+      if (k16 + 16 <= p.K) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = k16 + 4 * kq + s;
-        fb[slot][s] = (bn_ok && k < p.K) ? loadv<TN>(p.B + (long)k * p.ldb + n0 + TN * li) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 4; ++s) fb[slot][s] = bloadv<TN>(rsB, p.B, b_voff[s], goff);
+      } else {   // K tail (wgrad with a row count that is not a multiple of 16): rows >= K read as zero
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          fb[slot][s] = bloadv<TN>(rsB, p.B, (k16 + 4 * kq + s < p.K) ? b_voff[s] + goff : kOob, 0);
       }
     }
   };

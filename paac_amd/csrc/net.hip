@@ -51,11 +51,13 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-static GemmArgs make_args(const void* A, const float* B, float* out, const float* aux, int M, int N, int K, int ldb,
-                          int ldo) {
+static GemmArgs make_args(const void* A, size_t a_bytes, const float* B, size_t b_bytes, float* out, const float* aux,
+                          int M, int N, int K, int ldb, int ldo) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.out = out; g.aux = aux;
+  g.a_bytes = (unsigned)(a_bytes < 0x7FFFFFF0ull ? a_bytes : 0x7FFFFFF0ull);
+  g.b_bytes = (unsigned)(b_bytes < 0x7FFFFFF0ull ? b_bytes : 0x7FFFFFF0ull);
   g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldo = ldo;
   g.slab_rows = M;
 #ifdef PAAC_DMM_STAMPS
@@ -229,25 +231,25 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
 
   {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
-    GemmArgs g = make_args(states, w1, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
+    GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)256 * NT::C1 * 4, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
     launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
   }
   {
     ProfScope ps(ctx, F_CONV2_FWD, batch, s);
-    GemmArgs g = make_args(W.act[0], w2, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
+    GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
     launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
   }
   const float* last = W.act[1];
   if constexpr (NT::NCONV == 3) {
     ProfScope ps(ctx, F_CONV3_FWD, batch, s);
-    GemmArgs g = make_args(W.act[1], w3, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
+    GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
     launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);
     last = W.act[2];
   }
   int splits = 1;
   {
     ProfScope ps(ctx, F_FC_FWD, batch, s);
-    GemmArgs g = make_args(last, wf, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
+    GemmArgs g = make_args(last, (size_t)batch * NT::FLAT * 4, wf, (size_t)NT::FLAT * NT::H * 4, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
     g.slab_rows = batch;
     splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
   }
@@ -304,14 +306,14 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   }
   {
     ProfScope ps(ctx, F_FC_WGRAD, batch, side);
-    GemmArgs g = make_args(xf, ctx->dh, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
+    GemmArgs g = make_args(xf, (size_t)batch * NT::FLAT * 4, ctx->dh, (size_t)batch * NT::H * 4, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
     g.slab_rows = NT::FLAT + 1;
     launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, ctx->tune[OP_FC_WGRAD][cls], side);
   }
   // (3) fc dgrad, masked by relu'(last conv output)
   {
     ProfScope ps(ctx, F_FC_DGRAD, batch, s);
-    GemmArgs g = make_args(ctx->dh, wf, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
+    GemmArgs g = make_args(ctx->dh, (size_t)batch * NT::H * 4, wf, (size_t)NT::FLAT * NT::H * 4, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
     g.tapoff[0][0] = 0;
     launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, ctx->tune[OP_FC_DGRAD][cls], s);
   }
@@ -324,7 +326,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     {
       ProfScope ps(ctx, F_CONV3_WGRAD, batch, side);
       const int feats = NT::G3::FEATS;
-      GemmArgs g = make_args(W.act[1], ctx->dact[2], slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
+      GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
       g.slab_rows = feats + 1;
       const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], side);
       wgrad_out(i_w3, feats, NT::C3, slab, splits);
@@ -333,7 +335,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     // (5) conv3 dgrad -> dact[1] masked by relu'(a2)
     {
       ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
-      GemmArgs g = make_args(ctx->dact[2], w3, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
+      GemmArgs g = make_args(ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
       for (int kh = 0; kh < 3; ++kh)
         for (int kw = 0; kw < 3; ++kw) g.tapoff[0][kh * 3 + kw] = ((2 - kh) * 3 + (2 - kw)) * NT::C2 * NT::C3;
       launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
@@ -347,7 +349,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   {
     ProfScope ps(ctx, F_CONV2_WGRAD, batch, side);
     const int feats = NT::G2::FEATS;
-    GemmArgs g = make_args(W.act[0], ctx->dact[1], slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
+    GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
     g.slab_rows = feats + 1;
     const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], side);
     wgrad_out(i_w2, feats, NT::C2, slab, splits);
@@ -356,7 +358,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   // (7) conv2 dgrad by output parity (4 classes in blockIdx.z) -> dact[0] masked by relu'(a1)
   {
     ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
-    GemmArgs g = make_args(ctx->dact[1], w2, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
+    GemmArgs g = make_args(ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
     for (int par = 0; par < 4; ++par) {
       const int py = par >> 1, px = par & 1;
       for (int kh = 0; kh < 2; ++kh)
@@ -369,7 +371,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   {
     ProfScope ps(ctx, F_CONV1_WGRAD, batch, s);
     const int feats = 256;
-    GemmArgs g = make_args(states, ctx->dact[0], slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
+    GemmArgs g = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * 400 * NT::C1 * 4, slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
     g.slab_rows = feats + 1;
     const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
     wgrad_out(i_w1, feats, NT::C1, slab, splits);
