@@ -445,11 +445,13 @@ void default_tuning(paac_ctx* c) {
   if (c->cfg.arch != PAAC_ARCH_NATURE || c->max_batch > 512) return;
   c->tune[OP_CONV1_FWD][0] = Tune{2, 0, -1};
   c->tune[OP_CONV1_FWD][1] = Tune{4, 0, -1};
-  c->tune[OP_CONV2_FWD][1] = Tune{4, 0, -1};
-  c->tune[OP_FC_FWD][1] = Tune{3, 6, -1};
-  c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
+  c->tune[OP_CONV2_FWD][1] = Tune{7, 0, -1};
+  c->tune[OP_FC_FWD][0] = Tune{0, 8, 2};
+  c->tune[OP_FC_FWD][1] = Tune{1, 8, 2};
+  c->tune[OP_FC_WGRAD][1] = Tune{3, 1, 0};
   c->tune[OP_CONV3_WGRAD][1] = Tune{3, 48, 2};
-  c->tune[OP_CONV2_WGRAD][1] = Tune{3, 32, 2};
+  c->tune[OP_CONV3_DGRAD][1] = Tune{2, 0, -1};
+  c->tune[OP_CONV2_DGRAD][1] = Tune{3, 0, 0};
   c->tune[OP_CONV1_WGRAD][1] = Tune{2, 64, 2};
 }
 }  // namespace paac
