@@ -86,14 +86,15 @@ int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states
 
 /* Loss + gradients of policy_v_network.py:29-57 through the whole network (what
  * optimizer.compute_gradients(loss), actor_learner.py:44, evaluates): runs the training forward
- * on `states` (unless forward_done != 0: paac_train_forward already ran on the same batch), then backward; the
- * weight-gradient kernels run on an internal side stream concurrently with the data-gradient chain (fork/join
- * by events, so the call is still capturable and ordered on `stream`).  actions = sampled action index per row (the one-hot's argmax,
+ * on `states` (unless forward_done != 0: paac_train_forward already ran on the same batch), then backward.
+ * phase: 0 = everything; 1 = forward (unless done) + heads + fc layer -> the gradients of fc_w .. critic_b, i.e. the
+ * contiguous tail [offset(fc_w), total) of the flat buffer (95 % of its bytes); 2 = conv layers -> the head
+ * [0, offset(fc_w)).  A data-parallel caller all-reduces the tail while phase 2 still runs.  actions = sampled action index per row (the one-hot's argmax,
  * paac.py:27), y = critic target, adv = advantage, batch rows t-major (paac.py:151-154).
  * grad: flat, padded layout.  loss_out (nullable, device float[4]) = {loss, actor, critic, mean entropy}. */
 int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
                        const float* y, const float* adv, int batch, float entropy_beta,
-                       float* grad, float* loss_out, int forward_done, paac_stream_t stream);
+                       float* grad, float* loss_out, int forward_done, int phase, paac_stream_t stream);
 
 /* tf.clip_by_global_norm + RMSPropOptimizer.apply_gradients (actor_learner.py:31-34,56-59,70):
  *   g <- grad * grad_scale           (grad_scale = 1/world_size after the sum all-reduce)

@@ -147,14 +147,6 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
     PAAC_CHECK_HIP(hipMalloc(&c->dact[i], (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float)));
   }
   PAAC_CHECK_HIP(hipMalloc(&c->dh, (size_t)B * c->spec.fc * sizeof(float)));
-  // PAAC_FORK_WGRAD=1: run the weight-gradient kernels on a side stream (fork/join by events) concurrently with
-  // the data-gradient chain.  Off by default: on ROCm 7.2 each fork/join inside a replayed hipGraph costs
-  // 10-16 us, more than the overlap returns at the training batch of 160 (profiles/).
-  const char* fk = getenv("PAAC_FORK_WGRAD");
-  c->side = nullptr;
-  if (fk && fk[0] == '1') PAAC_CHECK_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (int i = 0; i < 4; ++i) PAAC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming));
-  PAAC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   c->wslab_floats = wslab_floats_needed(cfg->arch);
   PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
   PAAC_CHECK_HIP(hipMalloc(&c->partials, 4096 * sizeof(float)));
@@ -188,10 +180,6 @@ int paac_destroy(paac_ctx* c) {
   float* bufs[] = {c->dh, c->wslab, c->partials};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
-  if (c->side) (void)hipStreamDestroy(c->side);
-  for (int i = 0; i < 4; ++i)
-    if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
     if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
     if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -240,17 +228,19 @@ int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* state
 
 int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                        const float* adv, int batch, float entropy_beta, float* grad, float* loss_out,
-                       int forward_done, paac_stream_t stream) {
+                       int forward_done, int phase, paac_stream_t stream) {
   PAAC_REQUIRE(ctx && params && states && actions && y && adv && grad, "paac_loss_backward: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_loss_backward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
+  PAAC_REQUIRE(phase >= 0 && phase <= 2, "paac_loss_backward: phase %d", phase);
   int rc = 0;
-  if (!forward_done) {
+  if (!forward_done && phase != 2) {
     rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, (hipStream_t)stream);
     if (rc) return rc;
   }
   ctx->last_ws = 1;
-  rc = launch_backward(ctx, params, states, actions, y, adv, batch, entropy_beta, grad, loss_out, (hipStream_t)stream);
+  rc = launch_backward(ctx, params, states, actions, y, adv, batch, entropy_beta, grad, loss_out, phase,
+                       (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;

@@ -93,10 +93,6 @@ struct paac_ctx {
   int64_t wslab_floats;
   float* partials; // sum-of-squares partials
   int fc_splits_max;
-  // side stream + events: wgrad kernels run concurrently with the dgrad chain (fork/join, capturable)
-  hipStream_t side;
-  hipEvent_t ev_fork[4];
-  hipEvent_t ev_join;
   // profiling hooks
   int prof_on;
   static constexpr int PROF_MAX_EVENTS = 8192;
@@ -154,6 +150,6 @@ int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* sta
                           float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
                           uint32_t env_offset, int32_t* actions, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
-                    const float* adv, int batch, float beta, float* grad, float* loss_out, hipStream_t s);
+                    const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s);
 
 }  // namespace paac

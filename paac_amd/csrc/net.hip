@@ -261,15 +261,17 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   return 0;
 }
 
+// phase: 0 = whole backward; 1 = heads + fc (gradients of fc_w .. critic_b, the contiguous tail of the flat
+// buffer, 95 % of its bytes); 2 = conv layers (the head of the flat buffer) + slab finalize.  The split lets a
+// data-parallel caller all-reduce the tail while phase 2 still computes.
 template <class NT>
 static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
                          const float* y, const float* adv, int batch, float beta, float* grad, float* loss_out,
-                         hipStream_t s) {
+                         int phase, hipStream_t s) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[1];
   const int cls = batch > 64 ? 1 : 0;
-  const bool forked = ctx->side != nullptr;
-  hipStream_t side = forked ? ctx->side : s;   // wgrads run here, concurrently with the dgrad chain on `s`
+  hipStream_t side = s;   // (wgrad forked onto a side stream measured slower: 10-16 us per fork/join)
   const int A = ctx->cfg.num_actions;
   const int i_w1 = 0, i_w2 = 2, i_w3 = 4;
   const int i_wf = (NT::NCONV == 3) ? 6 : 4;
@@ -280,8 +282,9 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   const float* w2 = params + L.offset[i_w2];
   const float* w3 = (NT::NCONV == 3) ? params + L.offset[i_w3] : nullptr;
 
+  const bool do_fc = phase == 0 || phase == 1, do_conv = phase == 0 || phase == 2;
   // (1) heads: dH, head weight/bias grads, loss scalars
-  {
+  if (do_fc) {
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
     launch_heads_bwd<NT::H>(A, dim3(batch + NT::H / 32 + 1), s, (const float*)W.probs, (const float*)W.values, actions, y,
                             adv, (const float*)W.h, wa, wc, A, batch, beta, ctx->dh, grad + L.offset[i_wa],
@@ -299,30 +302,23 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     fin.seg[fin.nseg++] = FinalizeSeg{base, grad + L.offset[i_w], feats * cout, splits, stride};
     fin.seg[fin.nseg++] = FinalizeSeg{base + (long)feats * cout, grad + L.offset[i_w + 1], cout, splits, stride};
   };
-  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b   [side stream, needs dH]
-  if (forked) {
-    (void)hipEventRecord(ctx->ev_fork[0], s);
-    (void)hipStreamWaitEvent(side, ctx->ev_fork[0], 0);
-  }
-  {
+  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b
+  if (do_fc) {
     ProfScope ps(ctx, F_FC_WGRAD, batch, side);
     GemmArgs g = make_args(xf, (size_t)batch * NT::FLAT * 4, ctx->dh, (size_t)batch * NT::H * 4, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
     g.slab_rows = NT::FLAT + 1;
     launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, ctx->tune[OP_FC_WGRAD][cls], side);
   }
   // (3) fc dgrad, masked by relu'(last conv output)
-  {
+  if (do_fc) {
     ProfScope ps(ctx, F_FC_DGRAD, batch, s);
     GemmArgs g = make_args(ctx->dh, (size_t)batch * NT::H * 4, wf, (size_t)NT::FLAT * NT::H * 4, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
     g.tapoff[0][0] = 0;
     launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, ctx->tune[OP_FC_DGRAD][cls], s);
   }
+  if (!do_conv) return 0;
   if constexpr (NT::NCONV == 3) {
-    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3   [side stream, needs dact[2] from fc dgrad]
-    if (forked) {
-      (void)hipEventRecord(ctx->ev_fork[1], s);
-      (void)hipStreamWaitEvent(side, ctx->ev_fork[1], 0);
-    }
+    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3
     {
       ProfScope ps(ctx, F_CONV3_WGRAD, batch, side);
       const int feats = NT::G3::FEATS;
@@ -341,11 +337,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
     }
   }
-  // (6) conv2 wgrad   [side stream, needs dact[1]]
-  if (forked) {
-    (void)hipEventRecord(ctx->ev_fork[2], s);
-    (void)hipStreamWaitEvent(side, ctx->ev_fork[2], 0);
-  }
+  // (6) conv2 wgrad
   {
     ProfScope ps(ctx, F_CONV2_WGRAD, batch, side);
     const int feats = NT::G2::FEATS;
@@ -375,10 +367,6 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     g.slab_rows = feats + 1;
     const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
     wgrad_out(i_w1, feats, NT::C1, slab, splits);
-  }
-  if (forked) {
-    (void)hipEventRecord(ctx->ev_join, side);
-    (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
   }
   {
     ProfScope ps(ctx, F_GRAD_FINALIZE, batch, s);
@@ -414,10 +402,10 @@ int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* sta
 }
 
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
-                    const float* adv, int batch, float beta, float* grad, float* loss_out, hipStream_t s) {
+                    const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s) {
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return backward_impl<NatureNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, s);
-  return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, s);
+    return backward_impl<NatureNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, s);
+  return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, s);
 }
 
 #ifdef PAAC_DMM_STAMPS

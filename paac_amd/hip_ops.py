@@ -102,7 +102,8 @@ class Context(object):
                                                _ptr(states, torch.uint8, B * 28224, "states"), B, _stream()),
                    "paac_train_forward")
 
-    def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None, forward_done=False):
+    def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None, forward_done=False,
+                      phase=0):
         B = states.shape[0]
         if tuple(states.shape[1:]) != OBS_SHAPE:
             raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
@@ -115,7 +116,7 @@ class Context(object):
                                                float(entropy_beta),
                                                _ptr(grad, torch.float32, self.layout["total"], "grad"),
                                                _ptr(loss_out, torch.float32, 4, "loss_out", True),
-                                               1 if forward_done else 0, _stream()),
+                                               1 if forward_done else 0, int(phase), _stream()),
                    "paac_loss_backward")
 
     def clip_rmsprop(self, params, grad, ms, mom, lr_dev, decay, momentum, eps, clip_norm, clip_mode, grad_scale=1.0,

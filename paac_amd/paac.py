@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from . import hip_ops
+from . import hip_ops, parallel
 from .actor_learner import ActorLearner
 from .runners import EmulatorRunner, Runners
 
@@ -63,7 +63,11 @@ class DeviceRollout(object):
             self.mt_scratch = hip_ops.sample_mt_scratch(N, A, dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.graph_a = [None, None]
+        self.graph_conv = [None, None]
         self.graph_b = None
+        self.phased = L._world() > 1
+        # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
+        self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
         torch.cuda.synchronize(dev)
 
@@ -105,8 +109,15 @@ class DeviceRollout(object):
         hip_ops.nstep_returns_tick(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv,
                                    self.global_step_dev, self.total_envs * T, L.initial_lr, L.lr_annealing_steps,
                                    L.lr_dev, self.tick, T)
+        # one process: whole backward here; data parallel: heads + fc only (phase 1), so that the all-reduce of
+        # the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
         L.ctx.loss_backward(params, self.rollout_states(parity), self.actions.view(-1), self.y, self.adv,
-                            L.entropy_beta, L.grad, L.loss_dev)
+                            L.entropy_beta, L.grad, L.loss_dev, phase=1 if self.phased else 0)
+
+    def _backward_conv(self, parity):
+        L = self.L
+        L.ctx.loss_backward(L.network.params, self.rollout_states(parity), self.actions.view(-1), self.y, self.adv,
+                            L.entropy_beta, L.grad, L.loss_dev, forward_done=True, phase=2)
 
     def _update(self):
         L = self.L
@@ -126,6 +137,12 @@ class DeviceRollout(object):
                     self._update()
                 ga.end()
                 self.graph_a[parity] = ga
+                if world > 1:
+                    gc = hip_ops.Graph()
+                    gc.begin()
+                    self._backward_conv(parity)
+                    gc.end()
+                    self.graph_conv[parity] = gc
             if world > 1:
                 gb = hip_ops.Graph()
                 gb.begin()
@@ -139,14 +156,26 @@ class DeviceRollout(object):
                 if self.graph_a[0] is None:
                     self.capture()
                 self.graph_a[self.parity].launch()
-                if self.graph_b is not None:
-                    self.L._allreduce_grad()
+                if self.phased:
+                    self._exchange(self.graph_conv[self.parity].launch)
                     self.graph_b.launch()
             else:
                 self._rollout_and_backward(self.parity)
-                self.L._allreduce_grad()
+                if self.phased:
+                    self._exchange(lambda: self._backward_conv(self.parity))
                 self._update()
         self.parity ^= 1
+
+    def _exchange(self, conv_backward):
+        """Sum all-reduce of the flat gradient in two pieces: the fc/heads tail goes out (on the collective's own
+        stream) while `conv_backward` still computes the conv head on ours; the update waits for both."""
+        grad = self.L.grad
+        tail = parallel.allreduce_sum_async(grad[self.tail_offset:])
+        conv_backward()
+        head = parallel.allreduce_sum_async(grad[:self.tail_offset])
+        for work in (tail, head):
+            if work is not None:
+                work.wait()
 
     def synchronize(self):
         self.stream.synchronize()
@@ -162,10 +191,11 @@ class DeviceRollout(object):
         return count, [(float(rewards[i]), int(lens[i])) for i in idx]
 
     def close(self):
-        for g in (self.graph_a[0], self.graph_a[1], self.graph_b):
+        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b):
             if g is not None:
                 g.close()
         self.graph_a = [None, None]
+        self.graph_conv = [None, None]
         self.graph_b = None
 
 

@@ -35,6 +35,15 @@ def allreduce_sum_(flat_grad):
     return flat_grad
 
 
+def allreduce_sum_async(flat_grad):
+    """Start an in-place sum all-reduce; returns the work handle (None for a single process).  With RCCL the
+    collective runs on the process group's stream after the work already queued on the current stream, and
+    `work.wait()` makes the current stream wait for it -- no host synchronisation."""
+    if world_size() > 1:
+        return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
 def grad_scale():
     return 1.0 / world_size()
 

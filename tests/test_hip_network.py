@@ -110,6 +110,34 @@ def test_backward_parity(arch, A, B):
     ctx.close()
 
 
+@pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NIPS", 6, 24)])
+def test_backward_phases_compose(arch, A, B):
+    """phase 1 (heads + fc -> gradient tail) then phase 2 (conv -> gradient head) == phase 0, bit for bit; phase 1
+    alone leaves the conv head untouched (the data-parallel loop all-reduces the tail while phase 2 runs)."""
+    from paac_amd import hip_ops
+    params, states, idx, y, adv = make_case(arch, A, B, seed=5)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+    p = upload_params(ctx, params)
+    dev = [torch.from_numpy(a).cuda() for a in (states, idx, y, adv)]
+    whole = torch.zeros(ctx.layout["total"], device="cuda")
+    ctx.loss_backward(p, *dev, 0.02, whole)
+    tail = [t["offset"] for t in ctx.layout["tensors"] if t["name"].startswith("fc")][0]
+    split = torch.full((ctx.layout["total"],), 7.0, device="cuda")
+    ctx.loss_backward(p, *dev, 0.02, split, phase=1)
+    torch.cuda.synchronize()
+    assert torch.all(split[:tail] == 7.0)
+    assert torch.equal(split[tail:][whole[tail:] != 0], whole[tail:][whole[tail:] != 0])
+    ctx.loss_backward(p, *dev, 0.02, split, forward_done=True, phase=2)
+    torch.cuda.synchronize()
+    used = torch.zeros(ctx.layout["total"], dtype=torch.bool, device="cuda")
+    for t in ctx.layout["tensors"]:
+        used[t["offset"]:t["offset"] + t["size"]] = True
+    assert torch.equal(split[used], whole[used])
+    with pytest.raises(Exception):
+        ctx.loss_backward(p, *dev, 0.02, split, phase=3)
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode,gscale", [("global", 1.0), ("ignore", 1.0), ("global", 0.5)])
 def test_clip_rmsprop_parity(mode, gscale):
     from paac_amd import hip_ops, _lib
