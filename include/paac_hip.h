@@ -80,9 +80,13 @@ int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* state
                         float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
                         uint32_t env_offset, int32_t* actions, paac_stream_t stream);
 
-/* Training forward alone (into the ctx's TRAINING activation set, separate from the one paac_forward* use, so
- * a bootstrap inference may run concurrently on another stream).  Follow with paac_loss_backward(forward_done=1). */
-int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream);
+/* Training forward alone (into the ctx's TRAINING activation set, separate from the one paac_forward* use).
+ * Follow with paac_loss_backward(forward_done=1) on the same states with the same OR A SMALLER batch: activations
+ * are row-major per sample, so a caller may append the bootstrap observations (paac.py:140-142) as extra rows,
+ * read their values here, compute the returns, and run the backward over the first N*T rows only.
+ * values: nullable f32[batch]. */
+int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* values,
+                       paac_stream_t stream);
 
 /* Loss + gradients of policy_v_network.py:29-57 through the whole network (what
  * optimizer.compute_gradients(loss), actor_learner.py:44, evaluates): runs the training forward

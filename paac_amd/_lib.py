@@ -44,7 +44,7 @@ _SIGNATURES = {
     "paac_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "paac_forward_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_void_p, c_uint64,
                                     c_uint32, c_void_p, c_void_p]),
-    "paac_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "paac_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "paac_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "paac_clip_rmsprop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float,

@@ -73,7 +73,8 @@ class ActorLearner(object):
         self.train_step = Placeholder('train_step')
 
         self.ctx = hip_ops.Context(self.network.arch_id, self.num_actions,
-                                   max_batch=self.emulator_counts * self.max_local_steps, device_index=dev.index or 0)
+                                   max_batch=self.emulator_counts * (self.max_local_steps + 1),   # + bootstrap rows
+                                   device_index=dev.index or 0)
         self.session = Session(self.network, self.ctx, learner=self)
 
         scope = self.network.name

@@ -203,11 +203,12 @@ int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int 
   return 0;
 }
 
-int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream) {
+int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* values,
+                       paac_stream_t stream) {
   PAAC_REQUIRE(ctx && params && states, "paac_train_forward: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_train_forward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
-  const int rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, (hipStream_t)stream);
+  const int rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, values, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;

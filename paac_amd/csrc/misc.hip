@@ -560,6 +560,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// MOM = false: momentum == 0 (the reference's setting, actor_learner.py:31-34): the momentum slot is written (it
+// is checkpointed as OptimizerVariables_1) but not read.
+template <bool MOM>
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, const float* __restrict__ g,
                                                       float* __restrict__ ms, float* __restrict__ mom, long n4,
                                                       const float* __restrict__ lr_dev, float decay, float momentum,
@@ -588,13 +591,15 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
   if (i >= n4) return;
   float4 gv = reinterpret_cast<const float4*>(g)[i];
   float4 m = reinterpret_cast<float4*>(ms)[i];
-  float4 mo = reinterpret_cast<float4*>(mom)[i];
+  float4 mo = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (MOM) mo = reinterpret_cast<float4*>(mom)[i];
   float4 v = reinterpret_cast<float4*>(var)[i];
 #define PAAC_RMS(c)                                           \
   {                                                           \
     const float gg = gv.c * f;                                \
     m.c = m.c + (gg * gg - m.c) * omd;                        \
-    mo.c = momentum * mo.c + lr * gg / sqrtf(m.c + eps);      \
+    const float step = lr * gg / sqrtf(m.c + eps);            \
+    mo.c = MOM ? momentum * mo.c + step : step;               \
     v.c = v.c - mo.c;                                         \
   }
   PAAC_RMS(x) PAAC_RMS(y) PAAC_RMS(z) PAAC_RMS(w)
@@ -785,8 +790,12 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   ProfScope ps(ctx, F_CLIP_RMSPROP, (int)(n / 4), s);
   const long n4 = n / 4;
   launch_k(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), s, PROF_FIRST, grad, n4, grad_scale, ctx->partials);
-  launch_k(rmsprop_kernel, dim3((n4 + 255) / 256), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev, decay,
-           momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
+  if (momentum != 0.f)
+    launch_k(rmsprop_kernel<true>, dim3((n4 + 255) / 256), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
+             decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
+  else
+    launch_k(rmsprop_kernel<false>, dim3((n4 + 255) / 256), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
+             decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -5,6 +5,7 @@ extent on the host BEFORE the launch (a kernel that faults can take the whole no
 device pointers to libpaac_hip.so on torch's current HIP stream.
 """
 import ctypes
+import gc
 
 import numpy as np
 import torch
@@ -92,14 +93,15 @@ class Context(object):
                                                 int(env_offset), _ptr(actions, torch.int32, B, "actions"), _stream()),
                    "paac_forward_sample")
 
-    def train_forward(self, params, states):
+    def train_forward(self, params, states, values=None):
         B = states.shape[0]
         if tuple(states.shape[1:]) != OBS_SHAPE:
             raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
         if not (0 < B <= self.max_batch):
             raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
         _lib.check(self.lib.paac_train_forward(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
-                                               _ptr(states, torch.uint8, B * 28224, "states"), B, _stream()),
+                                               _ptr(states, torch.uint8, B * 28224, "states"), B,
+                                               _ptr(values, torch.float32, B, "values", True), _stream()),
                    "paac_train_forward")
 
     def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None, forward_done=False,
@@ -311,12 +313,38 @@ class Graph(object):
         self.handle = None
 
     def begin(self):
-        _lib.check(self.lib.paac_graph_begin(_stream()), "paac_graph_begin")
+        # A finalizer that frees device memory (a collected Context or tensor) in the middle of a capture
+        # invalidates it: collect now and keep the collector off until end().
+        gc.collect()
+        self._gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            _lib.check(self.lib.paac_graph_begin(_stream()), "paac_graph_begin")
+        except Exception:
+            self._restore_gc()
+            raise
+
+    def _restore_gc(self):
+        if getattr(self, "_gc_was_enabled", False):
+            gc.enable()
+        self._gc_was_enabled = False
 
     def end(self):
         h = ctypes.c_void_p()
-        _lib.check(self.lib.paac_graph_end(_stream(), ctypes.byref(h)), "paac_graph_end")
+        try:
+            _lib.check(self.lib.paac_graph_end(_stream(), ctypes.byref(h)), "paac_graph_end")
+        finally:
+            self._restore_gc()
         self.handle = h
+
+    def abort(self):
+        """Leave capture mode after a failed capture, dropping whatever was recorded."""
+        h = ctypes.c_void_p()
+        try:
+            if self.lib.paac_graph_end(_stream(), ctypes.byref(h)) == 0 and h:
+                self.lib.paac_graph_destroy(h)
+        finally:
+            self._restore_gc()
 
     def launch(self):
         _lib.check(self.lib.paac_graph_launch(self.handle, _stream()), "paac_graph_launch")

@@ -38,16 +38,19 @@ class DeviceRollout(object):
         self.sampler = sampler
         self.sampler_seed = int(sampler_seed)
         self.use_graph = use_graph
-        # Observation ring of 2T slots: even cycles use slots 0..T, odd cycles T..2T (slot 2T == slot 0), so the
-        # last observation of a cycle IS the first of the next one without a copy; two captured graphs alternate.
-        self.states = torch.zeros((2 * T, N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        # Observation buffer of 2T+1 slots: even cycles use slots 0..T, odd cycles T..2T, so the last observation of
+        # an even cycle IS the first of the odd one, and the T+1 observations of a cycle are contiguous (one
+        # forward at batch N*(T+1) serves the update and the bootstrap); an odd cycle ends by copying slot 2T to
+        # slot 0.  Two captured graphs alternate.
+        self.states = torch.zeros((2 * T + 1, N, 84, 84, 4), dtype=torch.uint8, device=dev)
+        self.values_train = torch.zeros(((T + 1) * N,), dtype=torch.float32, device=dev)
         self.parity = 0
         self.actions = torch.zeros((T, N), dtype=torch.int32, device=dev)
         self.values = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.rewards = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.masks = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.probs = torch.zeros((N, A), dtype=torch.float32, device=dev)
-        self.v_boot = torch.zeros((N,), dtype=torch.float32, device=dev)
+        self.v_boot = self.values_train[T * N:]
         self.y = torch.zeros((T * N,), dtype=torch.float32, device=dev)
         self.adv = torch.zeros((T * N,), dtype=torch.float32, device=dev)
         self.ep_reward = torch.zeros((N,), dtype=torch.float32, device=dev)
@@ -73,7 +76,7 @@ class DeviceRollout(object):
 
     # -- stages --------------------------------------------------------------------------------------
     def _slot(self, parity, t):
-        return (parity * self.T + t) % (2 * self.T)
+        return parity * self.T + t
 
     def rollout_states(self, parity=None):
         """[T*N,84,84,4] view of the states the LAST run cycle trained on (t-major, paac.py:151)."""
@@ -104,7 +107,11 @@ class DeviceRollout(object):
                                self.env_spec["terminal_threshold"], self.tick, t, st[t], st[t + 1],
                                self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
                                raw_scratch=self.raw)
-        L.ctx.forward(params, st[T], values=self.v_boot)                              # paac.py:140-142
+        if parity == 1:
+            self.states[0].copy_(self.states[2 * T])
+        # training forward over the T*N rollout rows with the N bootstrap observations appended (paac.py:140-142)
+        L.ctx.train_forward(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4),
+                            values=self.values_train)
         # returns + global_step/lr schedule + frame counter in one launch (paac.py:127,144-156)
         hip_ops.nstep_returns_tick(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv,
                                    self.global_step_dev, self.total_envs * T, L.initial_lr, L.lr_annealing_steps,
@@ -112,7 +119,7 @@ class DeviceRollout(object):
         # one process: whole backward here; data parallel: heads + fc only (phase 1), so that the all-reduce of
         # the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
         L.ctx.loss_backward(params, self.rollout_states(parity), self.actions.view(-1), self.y, self.adv,
-                            L.entropy_beta, L.grad, L.loss_dev, phase=1 if self.phased else 0)
+                            L.entropy_beta, L.grad, L.loss_dev, forward_done=True, phase=1 if self.phased else 0)
 
     def _backward_conv(self, parity):
         L = self.L
@@ -127,28 +134,30 @@ class DeviceRollout(object):
     def capture(self):
         """Capture the cycle into hipGraphs: one per observation-ring parity (and a separate update graph when a
         gradient all-reduce sits between backward and the optimizer step)."""
+        def captured(fn):
+            g = hip_ops.Graph()
+            g.begin()
+            try:
+                fn()
+            except Exception:
+                g.abort()
+                raise
+            g.end()
+            return g
+
+        def cycle(parity, with_update):
+            self._rollout_and_backward(parity)
+            if with_update:
+                self._update()
+
         with torch.cuda.stream(self.stream):
             world = self.L._world()
             for parity in (0, 1):
-                ga = hip_ops.Graph()
-                ga.begin()
-                self._rollout_and_backward(parity)
-                if world == 1:
-                    self._update()
-                ga.end()
-                self.graph_a[parity] = ga
+                self.graph_a[parity] = captured(lambda: cycle(parity, world == 1))
                 if world > 1:
-                    gc = hip_ops.Graph()
-                    gc.begin()
-                    self._backward_conv(parity)
-                    gc.end()
-                    self.graph_conv[parity] = gc
+                    self.graph_conv[parity] = captured(lambda: self._backward_conv(parity))
             if world > 1:
-                gb = hip_ops.Graph()
-                gb.begin()
-                self._update()
-                gb.end()
-                self.graph_b = gb
+                self.graph_b = captured(self._update)
 
     def run_cycle(self):
         with torch.cuda.stream(self.stream):

@@ -138,8 +138,38 @@ def test_backward_phases_compose(arch, A, B):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,gscale", [("global", 1.0), ("ignore", 1.0), ("global", 0.5)])
-def test_clip_rmsprop_parity(mode, gscale):
+@pytest.mark.parametrize("arch,A,N,T", [("NATURE", 4, 32, 5), ("NIPS", 6, 8, 3)])
+def test_train_forward_with_bootstrap_rows(arch, A, N, T):
+    """The device loop runs ONE training forward over N*T rollout rows + N bootstrap rows, reads the bootstrap
+    values from it and runs the backward over the first N*T rows: values must match paac_forward on the bootstrap
+    observations (paac.py:140-142) and the gradient must match the plain N*T-row call."""
+    from paac_amd import hip_ops
+    B = N * T
+    params, states, idx, y, adv = make_case(arch, A, B + N, seed=6)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B + N)
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    dev = [torch.from_numpy(a[:B]).cuda() for a in (idx, y, adv)]
+    want = torch.zeros(ctx.layout["total"], device="cuda")
+    ctx.loss_backward(p, s[:B], *dev, 0.02, want)
+    v_boot = torch.zeros(N, device="cuda")
+    ctx.forward(p, s[B:], values=v_boot)
+    got = torch.zeros(ctx.layout["total"], device="cuda")
+    values = torch.zeros(B + N, device="cuda")
+    ctx.train_forward(p, s, values=values)
+    ctx.loss_backward(p, s[:B], *dev, 0.02, got, forward_done=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(values[B:], v_boot, rtol=0, atol=1e-5)
+    ref = onet.forward(params, states[B:], arch, dtype=np.float64)
+    assert np.abs(values[B:].cpu().numpy() - ref["v"]).max() < 1e-4
+    scale = float(want.norm())
+    assert float((got - want).abs().max()) < 1e-6 * scale
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,gscale,momentum", [("global", 1.0, 0.0), ("ignore", 1.0, 0.0), ("global", 0.5, 0.0),
+                                                  ("global", 1.0, 0.9)])
+def test_clip_rmsprop_parity(mode, gscale, momentum):
     from paac_amd import hip_ops, _lib
     arch, A = "NATURE", 6
     ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=8)
@@ -148,12 +178,12 @@ def test_clip_rmsprop_parity(mode, gscale):
     var = rs.randn(n).astype(np.float32) * 0.1
     g = rs.randn(n).astype(np.float32) * (0.01 if mode == "global" else 0.001)
     ms = (1.0 + rs.rand(n)).astype(np.float32)
-    mom = np.zeros(n, dtype=np.float32)
+    mom = (rs.randn(n) * 1e-3).astype(np.float32)       # momentum 0 (the reference's setting): slot written, not read
     lr = np.float32(0.0224)
     dv, dg, dms, dmom = [torch.from_numpy(a.copy()).cuda() for a in (var, g, ms, mom)]
     lr_dev = torch.tensor([lr], device="cuda")
     gn_dev = torch.zeros(1, device="cuda")
-    ctx.clip_rmsprop(dv, dg, dms, dmom, lr_dev, 0.99, 0.0, 0.1, 3.0,
+    ctx.clip_rmsprop(dv, dg, dms, dmom, lr_dev, 0.99, momentum, 0.1, 3.0,
                      _lib.CLIP_GLOBAL if mode == "global" else _lib.CLIP_IGNORE, gscale, gn_dev)
     torch.cuda.synchronize()
     gs = g.astype(np.float64) * gscale
@@ -161,7 +191,7 @@ def test_clip_rmsprop_parity(mode, gscale):
     f = 3.0 * min(1.0 / gn, 1.0 / 3.0) if mode == "global" else 1.0
     gc = gs * f
     ms_e = ms + (gc * gc - ms) * 0.01
-    mom_e = lr * gc / np.sqrt(ms_e + 0.1)
+    mom_e = momentum * mom.astype(np.float64) + lr * gc / np.sqrt(ms_e + 0.1)
     var_e = var - mom_e
     assert abs(gn_dev.item() - gn) / gn < 1e-5
     assert np.abs(dms.cpu().numpy() - ms_e).max() < 1e-6
