@@ -49,8 +49,8 @@ def family_work(name, batch, arch, A, P):
              "conv3_fwd": conv3, "conv3_wgrad": conv3, "conv3_dgrad": conv3, "fc_fwd": fc, "fc_wgrad": fc, "fc_dgrad": fc}
     if name in table:
         return "flop", table[name]
-    if name == "clip_rmsprop":      # read g (norm) + read g, ms, mom, var + write ms, mom, var
-        return "byte", 4.0 * P * 8
+    if name == "clip_rmsprop":      # read g (norm) + read g, ms, var + write ms, mom, var (momentum 0: slot not read)
+        return "byte", 4.0 * P * 7
     if name == "heads_fwd":
         return "byte", 4.0 * batch * H * 2 + 4.0 * H * (A + 1)
     if name == "heads_bwd":

@@ -52,7 +52,10 @@ struct GemmArgs {
   int ldo;
   int groups_per_part;    // 16-wide K groups per (blockIdx.z, wk) part
   int slab_rows;          // EPI_SLAB: rows per slab (M, or M+1 with the bias-gradient row)
-  int tapoff[4][9];       // FRAG_K B: element offset of each (parity, tap)
+  // FRAG_K B (dgrad): element offset of tap t = (th, tw) of parity class z is
+  // tap_base[z] + th * tap_sh + tw * tap_sw  (th = t / G::KW, tw = t % G::KW) -- an affine walk over the flipped
+  // forward taps, so the K loop needs no table lookup (a scalar load + wait per group).
+  int tap_base[4], tap_sh, tap_sw;
   // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8;
   // observed, used for speed only) and every XCD has its own L2, which a kernel boundary leaves cold: an operand
   // slice read by workgroups on k different XCDs is fetched from the Infinity Cache k times.  xcd_dim names the
@@ -70,7 +73,7 @@ struct GemmArgs {
   do {                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     if (p.stamps && lane == 0)                                                                \
-      p.stamps[((long)blockIdx.x * (NWM * NWN * WK) + wave) * 8 + (i)] = \
+      p.stamps[((long)bid * (NWM * NWN * WK) + wave) * 8 + (i)] = \
           ((i) == 0 || (i) == 7) ? (unsigned long long)wall_clock64() : (unsigned long long)clock64();                          \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   } while (0)
@@ -114,16 +117,17 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 
 // NOTE (ROCm 7.2 hipcc): __builtin_amdgcn_raw_buffer_load_b64 is lowered to a single buffer_load_dword (the
-// second dword is garbage), so 8-byte fragments go through a plain global load off the uniform base pointer
-// (global_load_dwordx2 with an SGPR base + 32-bit VGPR offset); out-of-range lanes are zeroed by a select.
+// second dword is garbage), so 8-byte fragments are two dword buffer loads (same bytes through the texture
+// path; a plain global load + select for the range check would put an s_waitcnt right behind every load).
+// The scalar offset of a buffer instruction is NOT range-checked, so an operand whose K tail must read as zero
+// passes its whole offset in `voff`.
 template <int V>
-__device__ __forceinline__ f32x4 bloadv(__amdgpu_buffer_rsrc_t r, const void* base, unsigned voff, unsigned soff) {
+__device__ __forceinline__ f32x4 bloadv(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   if constexpr (V == 4) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
   } else if constexpr (V == 2) {
-    const bool ok = voff < kOob;
-    const float2 t = *reinterpret_cast<const float2*>(static_cast<const char*>(base) + (ok ? voff + soff : 0u));
-    return (f32x4){ok ? t.x : 0.f, ok ? t.y : 0.f, 0.f, 0.f};
+    return (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)),
+                   __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + 4u, soff, 0)), 0.f, 0.f};
   } else {
     return (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)), 0.f, 0.f, 0.f};
   }
@@ -154,19 +158,29 @@ __device__ __forceinline__ void storev(float* p, const f32x4 v) {
 
 // AP/BP: fragment pattern of A / B.  TM/TN: 16x16 tiles per wave (for a FRAG_MN side this is also the vector
 // width V in {1,2,4}).  NWM x NWN x WK waves per workgroup.  BCO: channels per tap of a FRAG_K B operand.
-template <class G, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI, bool BIASROW,
+// The contraction is a device-side body: one workgroup = one call of run(p, workgroup id, LDS).
+template <class G_, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI_, bool BIASROW,
           int PF>
-__global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs p) {
+struct Dmm {
+  using G = G_;
+  static constexpr int EPI = EPI_;
+  static constexpr int THREADS = 64 * NWM * NWN * WK;
+  static constexpr int M_TILE = NWM * TM * 16, N_TILE = NWN * TN * 16, WAVES_K = WK;
+  static constexpr int NA = (AP == FRAG_K) ? TM : 4;
+  static constexpr int NB = (BP == FRAG_K) ? TN : 4;
+  static constexpr int RING = PF + 1;
+  static constexpr int T = TM * TN;
+  static constexpr int LDS_F4 = (WK > 1) ? (NWM * NWN * WK * T * 64) : 1;
+  static constexpr int RED_F4 = LDS_F4 + (BIASROW ? NWN * WK * 16 : 0);
+  static constexpr int EPI_FLOATS = (BP == FRAG_K) ? NWM * NWN * WK * 16 * (TN * 16 + 4) : 4;
+  static constexpr int SMEM_BYTES = RED_F4 * 16 + EPI_FLOATS * 4;
   static_assert(AP == FRAG_K || TM == 1 || TM == 2 || TM == 4, "FRAG_MN A: TM is the vector width");
   static_assert(BP == FRAG_K || TN == 1 || TN == 2 || TN == 4, "FRAG_MN B: TN is the vector width");
   static_assert(!BIASROW || (BP == FRAG_MN && NWM == 1), "bias row needs dY as a FRAG_MN B operand and one M-wave");
-  constexpr int NA = (AP == FRAG_K) ? TM : 4;
-  constexpr int NB = (BP == FRAG_K) ? TN : 4;
-  constexpr int RING = PF + 1;
-  constexpr int T = TM * TN;
-  constexpr int LDS_F4 = (WK > 1) ? (NWM * NWN * WK * T * 64) : 1;
-  __shared__ f32x4 red[LDS_F4 + (BIASROW ? NWN * WK * 16 : 0)];
-  __shared__ __attribute__((aligned(16))) float epi[(BP == FRAG_K) ? NWM * NWN * WK * 16 * (TN * 16 + 4) : 4];
+
+  __device__ __forceinline__ static void run(const GemmArgs& p, const int bid, char* smem) {
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  float* epi = reinterpret_cast<float*>(smem + RED_F4 * 16);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -178,7 +192,6 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
   const int kq = lane >> 4;   // k-slot
   int bx, by, bz;
   {
-    const int bid = blockIdx.x;
     if (p.xcd_dim < 0) {
       bx = bid % p.MT;
       const int r = bid / p.MT;
@@ -264,24 +277,37 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
     for (int s = 0; s < 4; ++s) b_voff[s] = ok ? (unsigned)((4 * kq + s) * p.ldb + n0 + TN * li) * 4u : kOob;
   }
 
+  // ---- K range of this wave -------------------------------------------------------------------------
+  const int ngroups = (p.K + 15) / 16;
+  const int part = ((EPI == EPI_SLAB) ? z : 0) * WK + wk;
+  const int g_begin = min(part * p.groups_per_part, ngroups);
+  const int g_end = min(g_begin + p.groups_per_part, ngroups);
+  const int ng = g_end - g_begin;
+  const int k_end = min(p.K, g_end * 16);   // FRAG_MN A rows at or past this read as zero
+  const int tap_base = (BP == FRAG_K) ? p.tap_base[par] : 0;
+
   // ---- fragment loads for K group `g` (k16 = 16 g) --------------------------------------------------
+  // Every call issues the same NA + NB buffer loads whatever `live` is -- a group past the end of this wave's
+  // range is loaded with all lanes out of range (no memory access, zeros, never consumed) -- so the K loop has
+  // no branch around its loads and the compiler's s_waitcnt placement keeps the full prefetch distance.
   f32x4 fa[RING][NA], fb[RING][NB];
-  auto load_group = [&](int slot, int g) {
-    const int k16 = g * 16;   // wave-uniform
+  auto load_group = [&](int slot, int g, bool live) {
+    const int k16 = g * 16;                     // wave-uniform
+    const unsigned kill = live ? 0u : kOob;     // wave-uniform
     if constexpr (AP == FRAG_K) {
       const int kh = k16 / G::KWC;
       const int kwc = k16 - kh * G::KWC;
-      const unsigned goff = (unsigned)(kh * (G::IW * G::C) + kwc) * ES;
+      const unsigned goff = live ? (unsigned)(kh * (G::IW * G::C) + kwc) * ES : 0u;
       if constexpr (!G::PADDED) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) fa[slot][t] = bload4<U8>(rsA, a_voff[t], goff);
+        for (int t = 0; t < TM; ++t) fa[slot][t] = bload4<U8>(rsA, a_voff[t] | kill, goff);
       } else {
         const int kw = kwc / G::C;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
           const int iy = a_iy0[t] + kh;
           const int ix = a_ix0[t] + kw;
-          const bool ok = (iy >= 0) && (iy < G::IH) && (ix >= 0) && (ix < G::IW);
+          const bool ok = live && (iy >= 0) && (iy < G::IH) && (ix >= 0) && (ix < G::IW);
           fa[slot][t] = bload4<U8>(rsA, ok ? a_voff[t] + goff : kOob, 0);
         }
       }
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
       for (int s = 0; s < 4; ++s) {
         const int r = k16 + 4 * kq + s;
         unsigned off = kOob;
-        if (f_ok && r < p.K) {
+        if (f_ok && r < k_end) {
           const int b = r / G::OPIX;
           const int rem = r - b * G::OPIX;
           const int oy = rem / G::OW;
@@ -305,26 +331,24 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
           static_assert(!U8 || TM == 4, "u8 FRAG_MN loads are uchar4");
           fa[slot][s] = bload4<true>(rsA, off, 0);
         } else {
-          fa[slot][s] = bloadv<TM>(rsA, p.A, off, 0);
+          fa[slot][s] = bloadv<TM>(rsA, off, 0);
         }
       }
     }
     if constexpr (BP == FRAG_K) {
       const int tap = k16 / BCO;
       const int co = k16 - tap * BCO;
-      const unsigned goff = (unsigned)(p.tapoff[par][tap] + co) * 4u;
+      const int th = tap / G::KW;
+      const int tw = tap - th * G::KW;
+      const unsigned goff = live ? (unsigned)(tap_base + th * p.tap_sh + tw * p.tap_sw + co) * 4u : 0u;
 #pragma unroll
-      for (int t = 0; t < TN; ++t) fb[slot][t] = bload4<false>(rsB, b_voff[t], goff);
+      for (int t = 0; t < TN; ++t) fb[slot][t] = bload4<false>(rsB, b_voff[t] | kill, goff);
     } else {
-      const unsigned goff = (unsigned)(k16 * p.ldb) * 4u;
-      if (k16 + 16 <= p.K) {
+      // the whole offset goes through the range-checked VGPR offset: rows >= K (the tail of a K that is not a
+      // multiple of 16) and dead groups read as zero
+      const unsigned goff = live ? (unsigned)(k16 * p.ldb) * 4u : kOob;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fb[slot][s] = bloadv<TN>(rsB, p.B, b_voff[s], goff);
-      } else {   // K tail (wgrad with a row count that is not a multiple of 16): rows >= K read as zero
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          fb[slot][s] = bloadv<TN>(rsB, p.B, (k16 + 4 * kq + s < p.K) ? b_voff[s] + goff : kOob, 0);
-      }
+      for (int s = 0; s < 4; ++s) fb[slot][s] = bloadv<TN>(rsB, b_voff[s] + goff, 0);
     }
   };
 
@@ -335,42 +359,74 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- K range of this wave -------------------------------------------------------------------------
-  const int ngroups = (p.K + 15) / 16;
-  const int part = ((EPI == EPI_SLAB) ? z : 0) * WK + wk;
-  const int g_begin = min(part * p.groups_per_part, ngroups);
-  const int g_end = min(g_begin + p.groups_per_part, ngroups);
-  const int ng = g_end - g_begin;
+  // bias of this lane's TN output columns: issued ahead of the K loop, consumed in the epilogue
+  f32x4 biasv = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == EPI_BIAS_RELU) {
+    if (n0 + TN * li < p.N) biasv = loadv<TN>(p.aux + n0 + TN * li);
+  }
 
   DMM_STAMP(2);
 #pragma unroll
-  for (int s = 0; s < PF; ++s)
-    if (s < ng) load_group(s, g_begin + s);
+  for (int s = 0; s < PF; ++s) load_group(s, g_begin + s, s < ng);
   DMM_STAMP(3);
-  for (int gb = 0; gb < ng; gb += RING) {
+  for (int gb = 0;; gb += RING) {
 #pragma unroll
     for (int st = 0; st < RING; ++st) {
       const int gi = gb + st;
-      if (gi < ng) {
-        if (gi + PF < ng) load_group((st + PF) % RING, g_begin + gi + PF);
+      if (gi >= ng) goto k_done;   // side exit: nothing joins the loop body, the wait counts stay exact
+      load_group((st + PF) % RING, g_begin + gi + PF, gi + PF < ng);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float av = (AP == FRAG_K) ? fa[st][i][s] : fa[st][s][i];
+        for (int i = 0; i < TM; ++i) {
+          const float av = (AP == FRAG_K) ? fa[st][i][s] : fa[st][s][i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float bv = (BP == FRAG_K) ? fb[st][j][s] : fb[st][s][j];
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
-            }
+          for (int j = 0; j < TN; ++j) {
+            const float bv = (BP == FRAG_K) ? fb[st][j][s] : fb[st][s][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
           }
-          if constexpr (BIASROW) bsum += fb[st][s];
         }
+        if constexpr (BIASROW) bsum += fb[st][s];
+      }
+    }
+  }
+k_done:
+
+  DMM_STAMP(4);
+  // ---- dgrad: fetch the activations the ReLU mask is derived from now (the ring registers are dead), so the
+  // loads overlap the LDS reduce / transpose instead of sitting exposed between the transpose and the store
+  constexpr int F4_PER_ROW = TN * 4;
+  constexpr int ROWS_PER_PASS = 64 / F4_PER_ROW;
+  constexpr int PASSES = (BP == FRAG_K) ? 16 / ROWS_PER_PASS : 1;
+  f32x4 mk[(BP == FRAG_K) ? TM : 1][PASSES];
+  int mk_off[(BP == FRAG_K) ? TM : 1][PASSES];   // element offset of the lane's float4 in out / aux, -1 = none
+  if constexpr (BP == FRAG_K) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if ((tm % WK) != wk) continue;
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int row = pass * ROWS_PER_PASS + lane / F4_PER_ROW;
+        const int m = m0 + tm * 16 + row;
+        const int n = n0 + (lane % F4_PER_ROW) * 4;
+        int off = -1;
+        if (m < p.M && n < p.N) {
+          int orow = m;
+          if constexpr (EPI == EPI_MASK_PARITY) {
+            const int b = m / G::OPIX;
+            const int rem = m - b * G::OPIX;
+            const int a = rem / G::OW;
+            const int cc = rem - a * G::OW;
+            orow = (b * (2 * G::OH) + 2 * a + (z >> 1)) * (2 * G::OW) + 2 * cc + (z & 1);
+          }
+          off = orow * p.ldo + n;
+          mk[tm][pass] = *reinterpret_cast<const f32x4*>(p.aux + off);
+        }
+        mk_off[tm][pass] = off;
       }
     }
   }
 
-  DMM_STAMP(4);
   // ---- sum the WK partials through LDS ----------------------------------------------------------------
   const int grp = wm * NWN + wn;
   if constexpr (WK > 1) {
@@ -409,9 +465,8 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) v[tn] = c[tn][r];
         if constexpr (EPI == EPI_BIAS_RELU) {
-          const f32x4 bb = loadv<TN>(p.aux + n);
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) v[tn] = fmaxf(v[tn] + bb[tn], 0.f);
+          for (int tn = 0; tn < TN; ++tn) v[tn] = fmaxf(v[tn] + biasv[tn], 0.f);
           storev<TN>(p.out + (long)m * p.ldo + n, v);
         } else {
           static_assert(BP != FRAG_MN || EPI == EPI_BIAS_RELU || EPI == EPI_SLAB, "FRAG_MN B epilogues");
@@ -431,28 +486,17 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
         for (int tn = 0; tn < TN; ++tn) et[(4 * q + r) * EW + tn * 16 + li] = c[tn][r];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      constexpr int F4_PER_ROW = TN * 4;
-      constexpr int ROWS_PER_PASS = 64 / F4_PER_ROW;
 #pragma unroll
-      for (int pass = 0; pass < 16 / ROWS_PER_PASS; ++pass) {
+      for (int pass = 0; pass < PASSES; ++pass) {
         const int row = pass * ROWS_PER_PASS + lane / F4_PER_ROW;
         const int c4 = (lane % F4_PER_ROW) * 4;
-        const int m = m0 + tm * 16 + row;
-        const int n = n0 + c4;
-        if (m < p.M && n < p.N) {
-          long orow = m;
-          if constexpr (EPI == EPI_MASK_PARITY) {
-            const int b = m / G::OPIX;
-            const int rem = m - b * G::OPIX;
-            const int a = rem / G::OW;
-            const int cc = rem - a * G::OW;
-            orow = ((long)b * (2 * G::OH) + 2 * a + (z >> 1)) * (2 * G::OW) + 2 * cc + (z & 1);
-          }
-          const f32x4 act = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + n);
+        const int off = mk_off[tm][pass];
+        if (off >= 0) {
+          const f32x4 act = mk[tm][pass];
           f32x4 v = *reinterpret_cast<const f32x4*>(et + row * EW + c4);
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) v[e4] = act[e4] > 0.f ? v[e4] : 0.f;
-          *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n) = v;
+          *reinterpret_cast<f32x4*>(p.out + off) = v;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -487,16 +531,23 @@ __global__ __launch_bounds__(64 * NWM * NWN * WK) void dmm_kernel(const GemmArgs
         storev<TN>(p.out + ((long)z * p.slab_rows + p.M) * p.ldo + n0 + TN * li, bsum);
     }
   }
+  }   // run
+};
+
+template <class D>
+__global__ __launch_bounds__(D::THREADS) void dmm_kernel(const GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[D::SMEM_BYTES];
+  D::run(p, blockIdx.x, smem);
 }
 
-template <class G, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI, bool BIASROW,
-          int PF>
-inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, int xcd_dim, hipStream_t s) {
+// Fills the launch geometry of `a` for body D; returns the number of workgroups.
+template <class D>
+inline long prepare_dmm(GemmArgs& a, int zdim, int ksplit_z, int xcd_dim) {
   const int ngroups = (a.K + 15) / 16;
-  const int parts = WK * ((EPI == EPI_SLAB) ? ksplit_z : 1);
+  const int parts = D::WAVES_K * ((D::EPI == EPI_SLAB) ? ksplit_z : 1);
   a.groups_per_part = (ngroups + parts - 1) / parts;
-  a.MT = (a.M + NWM * TM * 16 - 1) / (NWM * TM * 16);
-  a.NT = (a.N + NWN * TN * 16 - 1) / (NWN * TN * 16);
+  a.MT = (a.M + D::M_TILE - 1) / D::M_TILE;
+  a.NT = (a.N + D::N_TILE - 1) / D::N_TILE;
   a.Z = zdim;
   static const int xcd_mask = []() { const char* v = getenv("PAAC_TUNE_XCD"); return (v && *v) ? atoi(v) : 7; }();
   a.xcd_dim = (xcd_dim >= 0 && ((xcd_mask >> xcd_dim) & 1)) ? xcd_dim : -1;   // tuning knob: bit d enables dim d
@@ -505,8 +556,13 @@ inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, int xcd_dim, hipStrea
   if (xcd_dim == 0) blocks = (long)((a.MT + 7) / 8) * 8 * a.NT * a.Z;
   if (xcd_dim == 1) blocks = (long)((a.NT + 7) / 8) * 8 * a.MT * a.Z;
   if (xcd_dim == 2) blocks = (long)((a.Z + 7) / 8) * 8 * a.MT * a.NT;
-  launch_k(dmm_kernel<G, U8, AP, BP, TM, TN, NWM, NWN, WK, BCO, EPI, BIASROW, PF>, dim3((unsigned)blocks),
-           dim3(64 * NWM * NWN * WK), s, PROF_WHOLE, a);
+  return blocks;
+}
+
+template <class D>
+inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, int xcd_dim, hipStream_t s) {
+  const long blocks = prepare_dmm<D>(a, zdim, ksplit_z, xcd_dim);
+  launch_k(dmm_kernel<D>, dim3((unsigned)blocks), dim3(D::THREADS), s, PROF_WHOLE, a);
 }
 
 }  // namespace paac

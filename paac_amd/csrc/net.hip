@@ -84,12 +84,15 @@ static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int targe
 // XCD-tied grid dimension.
 //                      id TM NWM WK PF
 #define PAAC_FWD_CFGS(X) X(0, 1, 1, 8, 5) X(1, 1, 1, 4, 5) X(2, 2, 1, 8, 3) X(3, 2, 1, 4, 3) X(4, 2, 2, 2, 2) \
-                         X(5, 2, 4, 1, 2) X(6, 1, 2, 4, 4) X(7, 2, 2, 4, 2)
+                         X(5, 2, 4, 1, 2) X(6, 1, 2, 4, 4) X(7, 2, 2, 4, 2) X(8, 2, 2, 1, 3) X(9, 1, 4, 1, 4) \
+                         X(10, 4, 1, 2, 2) X(11, 4, 2, 1, 2) X(12, 2, 1, 2, 3)
 #define PAAC_DGRAD_CFGS(X) X(0, 1, 1, 8, 4) X(1, 2, 1, 4, 4) X(2, 2, 2, 2, 3) X(3, 2, 4, 1, 2) X(4, 1, 1, 4, 4) \
-                           X(5, 2, 1, 8, 3) X(6, 1, 2, 4, 4)
+                           X(5, 2, 1, 8, 3) X(6, 1, 2, 4, 4) X(7, 2, 2, 1, 3) X(8, 1, 4, 1, 4) X(9, 4, 1, 2, 2)  \
+                           X(10, 4, 2, 1, 2) X(11, 2, 1, 2, 3)
 //                        id TM WK PF
-#define PAAC_WGRAD_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(2, 4, 8, 2) X(3, 4, 4, 3) X(4, 2, 4, 3) X(5, 2, 8, 3)
-constexpr int kFwdCfgs = 8, kDgradCfgs = 7, kWgradCfgs = 6;
+#define PAAC_WGRAD_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(2, 4, 8, 2) X(3, 4, 4, 3) X(4, 2, 4, 3) X(5, 2, 8, 3) X(6, 4, 1, 3) \
+                           X(7, 4, 1, 4) X(8, 4, 2, 3)
+constexpr int kFwdCfgs = 13, kDgradCfgs = 12, kWgradCfgs = 9;
 
 // Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
 template <class G, bool U8, int NDIM, int EPI>
@@ -111,7 +114,7 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
   }
   switch (cfg) {
 #define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF>(g, ksplit, ksplit, xcd, s); break;
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF>>(g, ksplit, ksplit, xcd, s); break;
     PAAC_FWD_CFGS(X)
 #undef X
     default: break;
@@ -120,18 +123,32 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
 }
 
 // dgrad: A = FRAG_K patches of dY, B = FRAG_K taps of W^T.
-template <class G, int NDIM, int BCO, int EPI>
-static void launch_dgrad(const GemmArgs& g, int zdim, Tune t, hipStream_t s) {
-  constexpr int TN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
-  int cfg = t.cfg, xcd = t.xcd;
+template <int NDIM>
+struct DgradN {
+  static constexpr int TN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+};
+template <class G, int NDIM, int BCO, int EPI, int TM, int NWM, int WK, int PF>
+using DgradBody = Dmm<G, false, FRAG_K, FRAG_K, TM, DgradN<NDIM>::TN, NWM, 1, WK, BCO, EPI, false, PF>;
+
+template <int NDIM, int EPI>
+static void resolve_dgrad(const GemmArgs& g, int zdim, Tune t, int& cfg, int& xcd) {
+  constexpr int TN = DgradN<NDIM>::TN;
+  cfg = t.cfg;
+  xcd = t.xcd;
   if (cfg < 0) {
     const long tiles = (long)((g.M + 31) / 32) * ((g.N + 16 * TN - 1) / (16 * TN)) * zdim;
     cfg = (tiles <= 384) ? 1 : (tiles <= 1536) ? 2 : 3;
     xcd = (EPI == EPI_MASK_PARITY) ? 0 : -1;
   }
+}
+
+template <class G, int NDIM, int BCO, int EPI>
+static void launch_dgrad(const GemmArgs& g, int zdim, Tune t, hipStream_t s) {
+  int cfg, xcd;
+  resolve_dgrad<NDIM, EPI>(g, zdim, t, cfg, xcd);
   switch (cfg) {
 #define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<G, false, FRAG_K, FRAG_K, TM, TN, NWM, 1, WK, BCO, EPI, false, PF>(g, zdim, 1, xcd, s); break;
+  case id: launch_dmm<DgradBody<G, NDIM, BCO, EPI, TM, NWM, WK, PF>>(g, zdim, 1, xcd, s); break;
     PAAC_DGRAD_CFGS(X)
 #undef X
     default: break;
@@ -139,11 +156,20 @@ static void launch_dgrad(const GemmArgs& g, int zdim, Tune t, hipStream_t s) {
 }
 
 // wgrad: A = FRAG_MN patches^T (16*TM features per wave), B = FRAG_MN dY; split-K slabs + bias-gradient row.
-template <class G, bool U8, int NDIM>
-static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s) {
-  constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+template <int NDIM>
+struct WgradN {
+  static constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+};
+template <class G, bool U8, int NDIM, int TM, int WK, int PF>
+using WgradBody = Dmm<G, U8, FRAG_MN, FRAG_MN, TM, WgradN<NDIM>::VN, 1, 1, WK, 1, EPI_SLAB, true, PF>;
+
+template <bool U8, int NDIM>
+static void resolve_wgrad(const GemmArgs& g, int max_split, Tune t, int& cfg, int& ks, int& xcd) {
+  constexpr int VN = WgradN<NDIM>::VN;
   const int ngroups = (g.K + 15) / 16;
-  int cfg = t.cfg, ks = t.ksplit, xcd = t.xcd;
+  cfg = t.cfg;
+  ks = t.ksplit;
+  xcd = t.xcd;
   if (cfg < 0) {
     const long tiles = (long)((g.M + 63) / 64) * ((g.N + 16 * VN - 1) / (16 * VN));
     if (ngroups >= 64 && max_split >= 8) {
@@ -159,11 +185,16 @@ static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s)
   if (ks < 1) ks = 1;
   if (ks > max_split) ks = max_split;
   if (U8 && (cfg == 4 || cfg == 5)) cfg = 0;   // u8 patches are loaded as uchar4: 64 features per wave only
+}
+
+template <class G, bool U8, int NDIM>
+static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s) {
+  int cfg, ks, xcd;
+  resolve_wgrad<U8, NDIM>(g, max_split, t, cfg, ks, xcd);
   switch (cfg) {
-#define X(id, TM, WK, PF)                                                                                     \
-  case id:                                                                                                    \
-    if constexpr (!U8 || TM == 4)                                                                             \
-      launch_dmm<G, U8, FRAG_MN, FRAG_MN, TM, VN, 1, 1, WK, 1, EPI_SLAB, true, PF>(g, ks, ks, xcd, s);        \
+#define X(id, TM, WK, PF)                                                                   \
+  case id:                                                                                  \
+    if constexpr (!U8 || TM == 4) launch_dmm<WgradBody<G, U8, NDIM, TM, WK, PF>>(g, ks, ks, xcd, s); \
     break;
     PAAC_WGRAD_CFGS(X)
 #undef X
@@ -271,7 +302,6 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[1];
   const int cls = batch > 64 ? 1 : 0;
-  hipStream_t side = s;   // (wgrad forked onto a side stream measured slower: 10-16 us per fork/join)
   const int A = ctx->cfg.num_actions;
   const int i_w1 = 0, i_w2 = 2, i_w3 = 4;
   const int i_wf = (NT::NCONV == 3) ? 6 : 4;
@@ -302,62 +332,61 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     fin.seg[fin.nseg++] = FinalizeSeg{base, grad + L.offset[i_w], feats * cout, splits, stride};
     fin.seg[fin.nseg++] = FinalizeSeg{base + (long)feats * cout, grad + L.offset[i_w + 1], cout, splits, stride};
   };
-  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b
+  // (A layer's weight and data gradient sharing one launch -- both wait only on dY -- was measured: the paired
+  // kernel takes the SUM of the two times, their main loops already keep the MFMA pipes of the CUs they occupy busy.)
+  // (2) fc wgrad (+ bias row): [FLAT+1][H] = fc_w then fc_b;  (3) fc dgrad, masked by relu'(last conv output)
   if (do_fc) {
-    ProfScope ps(ctx, F_FC_WGRAD, batch, side);
-    GemmArgs g = make_args(xf, (size_t)batch * NT::FLAT * 4, ctx->dh, (size_t)batch * NT::H * 4, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
-    g.slab_rows = NT::FLAT + 1;
-    launch_wgrad<typename NT::GFC, false, NT::H>(g, 1, ctx->tune[OP_FC_WGRAD][cls], side);
-  }
-  // (3) fc dgrad, masked by relu'(last conv output)
-  if (do_fc) {
+    GemmArgs gw = make_args(xf, (size_t)batch * NT::FLAT * 4, ctx->dh, (size_t)batch * NT::H * 4, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
+    gw.slab_rows = NT::FLAT + 1;
+    GemmArgs gd = make_args(ctx->dh, (size_t)batch * NT::H * 4, wf, (size_t)NT::FLAT * NT::H * 4, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
+    {
+      ProfScope ps(ctx, F_FC_WGRAD, batch, s);
+      launch_wgrad<typename NT::GFC, false, NT::H>(gw, 1, ctx->tune[OP_FC_WGRAD][cls], s);
+    }
     ProfScope ps(ctx, F_FC_DGRAD, batch, s);
-    GemmArgs g = make_args(ctx->dh, (size_t)batch * NT::H * 4, wf, (size_t)NT::FLAT * NT::H * 4, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
-    g.tapoff[0][0] = 0;
-    launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(g, 1, ctx->tune[OP_FC_DGRAD][cls], s);
+    launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(gd, 1, ctx->tune[OP_FC_DGRAD][cls], s);
   }
   if (!do_conv) return 0;
   if constexpr (NT::NCONV == 3) {
-    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3
+    // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3;  (5) conv3 dgrad -> dact[1] masked by relu'(a2)
+    const int feats = NT::G3::FEATS;
+    GemmArgs gw = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
+    gw.slab_rows = feats + 1;
+    GemmArgs gd = make_args(ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
+    // tap (kh, kw) of the full correlation reads the forward tap (2 - kh, 2 - kw)
+    gd.tap_base[0] = 8 * NT::C2 * NT::C3;
+    gd.tap_sh = -3 * NT::C2 * NT::C3;
+    gd.tap_sw = -NT::C2 * NT::C3;
+    int splits;
     {
-      ProfScope ps(ctx, F_CONV3_WGRAD, batch, side);
-      const int feats = NT::G3::FEATS;
-      GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
-      g.slab_rows = feats + 1;
-      const int splits = launch_wgrad<typename NT::G3, false, NT::C3>(g, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], side);
-      wgrad_out(i_w3, feats, NT::C3, slab, splits);
-      slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
+      ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
+      splits = launch_wgrad<typename NT::G3, false, NT::C3>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], s);
     }
-    // (5) conv3 dgrad -> dact[1] masked by relu'(a2)
-    {
-      ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
-      GemmArgs g = make_args(ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
-      for (int kh = 0; kh < 3; ++kh)
-        for (int kw = 0; kw < 3; ++kw) g.tapoff[0][kh * 3 + kw] = ((2 - kh) * 3 + (2 - kw)) * NT::C2 * NT::C3;
-      launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(g, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
-    }
+    ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
+    launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(gd, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
+    wgrad_out(i_w3, feats, NT::C3, slab, splits);
+    slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
   }
-  // (6) conv2 wgrad
+  // (6) conv2 wgrad;  (7) conv2 dgrad by output parity (4 classes in blockIdx.z) -> dact[0] masked by relu'(a1)
   {
-    ProfScope ps(ctx, F_CONV2_WGRAD, batch, side);
     const int feats = NT::G2::FEATS;
-    GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
-    g.slab_rows = feats + 1;
-    const int splits = launch_wgrad<typename NT::G2, false, NT::C2>(g, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], side);
+    GemmArgs gw = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
+    gw.slab_rows = feats + 1;
+    GemmArgs gd = make_args(ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
+    // output parity (py, px), tap (kh, kw) of the 2x2 dense correlation reads forward tap
+    // (py + 2 (1 - kh), px + 2 (1 - kw)) of the 4x4 kernel
+    for (int par = 0; par < 4; ++par) gd.tap_base[par] = (((par >> 1) + 2) * 4 + (par & 1) + 2) * NT::C1 * NT::C2;
+    gd.tap_sh = -8 * NT::C1 * NT::C2;
+    gd.tap_sw = -2 * NT::C1 * NT::C2;
+    int splits;
+    {
+      ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
+      splits = launch_wgrad<typename NT::G2, false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], s);
+    }
+    ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
+    launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(gd, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
     wgrad_out(i_w2, feats, NT::C2, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C2;
-  }
-  // (7) conv2 dgrad by output parity (4 classes in blockIdx.z) -> dact[0] masked by relu'(a1)
-  {
-    ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
-    GemmArgs g = make_args(ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
-    for (int par = 0; par < 4; ++par) {
-      const int py = par >> 1, px = par & 1;
-      for (int kh = 0; kh < 2; ++kh)
-        for (int kw = 0; kw < 2; ++kw)
-          g.tapoff[par][kh * 2 + kw] = ((py + 2 * (1 - kh)) * 4 + (px + 2 * (1 - kw))) * NT::C1 * NT::C2;
-    }
-    launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(g, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
   }
   // (8) conv1 wgrad from the u8 frames
   {
@@ -431,14 +460,20 @@ namespace paac {
 // heuristics.
 void default_tuning(paac_ctx* c) {
   if (c->cfg.arch != PAAC_ARCH_NATURE || c->max_batch > 512) return;
-  c->tune[OP_CONV1_FWD][0] = Tune{2, 0, -1};
+  // tools/tune_gemm.py on MI355X, 32 envs x t_max 5: acting batch 32 (class 0); training forward over 192 rows and
+  // backward over 160 (class 1)
+  c->tune[OP_CONV1_FWD][0] = Tune{7, 0, -1};
   c->tune[OP_CONV1_FWD][1] = Tune{4, 0, -1};
   c->tune[OP_CONV2_FWD][1] = Tune{7, 0, -1};
+  c->tune[OP_CONV3_FWD][0] = Tune{1, 0, -1};
+  c->tune[OP_CONV3_FWD][1] = Tune{7, 0, -1};
   c->tune[OP_FC_FWD][0] = Tune{0, 8, 2};
-  c->tune[OP_FC_FWD][1] = Tune{1, 8, 2};
-  c->tune[OP_FC_WGRAD][1] = Tune{3, 1, 0};
-  c->tune[OP_CONV3_WGRAD][1] = Tune{3, 48, 2};
+  c->tune[OP_FC_FWD][1] = Tune{3, 8, 2};
+  c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
+  c->tune[OP_FC_DGRAD][1] = Tune{5, 0, -1};
+  c->tune[OP_CONV3_WGRAD][1] = Tune{0, 48, 2};
   c->tune[OP_CONV3_DGRAD][1] = Tune{2, 0, -1};
+  c->tune[OP_CONV2_WGRAD][1] = Tune{3, 32, 2};
   c->tune[OP_CONV2_DGRAD][1] = Tune{3, 0, 0};
   c->tune[OP_CONV1_WGRAD][1] = Tune{2, 64, 2};
 }

@@ -13,9 +13,9 @@ N = int(os.environ.get("TUNE_N", "32"))
 T = int(os.environ.get("TUNE_T", "5"))
 dev = torch.device("cuda", 0)
 lib = _lib.load()
-ctx = hip_ops.Context(ARCH, A, max_batch=N * T)
+ctx = hip_ops.Context(ARCH, A, max_batch=N * (T + 1))
 P = torch.randn(ctx.layout["total"], device=dev) * 0.02
-S = torch.randint(0, 255, (N * T, 84, 84, 4), dtype=torch.uint8, device=dev)
+S = torch.randint(0, 255, (N * (T + 1), 84, 84, 4), dtype=torch.uint8, device=dev)
 probs = torch.zeros(N, A, device=dev); vals = torch.zeros(N, device=dev)
 grad = torch.zeros(ctx.layout["total"], device=dev)
 acts = torch.zeros(N * T, dtype=torch.int32, device=dev)
@@ -54,29 +54,30 @@ def fwd_act():
     ctx.forward(P, S[:N], probs=probs, values=vals)
 
 
-def train():
-    ctx.loss_backward(P, S, acts, yy, aa, 0.02, grad)
+def train():     # what the device loop runs per update: forward over N*(T+1) rows, backward over N*T
+    ctx.train_forward(P, S)
+    ctx.loss_backward(P, S[:N * T], acts, yy, aa, 0.02, grad, forward_done=True)
 
 
 def candidates(op, cls):
     fam = "fwd" if op <= 3 else ("dgrad" if op in (5, 7, 9) else "wgrad")
     out = []
     if fam == "fwd" and op != 3:
-        out = [(c, 0, -1) for c in range(8)]
+        out = [(c, 0, -1) for c in range(13)]
     elif op == 3:
-        for c in range(8):
-            for ks in (1, 2, 3, 4, 6, 8):
+        for c in range(13):
+            for ks in (1, 2, 4, 8):
                 out.append((c, ks, -1))
                 if ks == 8:
                     out.append((c, ks, 2))
     elif fam == "dgrad":
-        out = [(c, 0, x) for c in range(7) for x in (-1, 0, 1)]
+        out = [(c, 0, x) for c in range(12) for x in (-1, 0, 1)]
     elif op == 4:
-        out = [(c, 1, x) for c in range(6) for x in (-1, 0, 1)]
+        out = [(c, 1, x) for c in range(9) for x in (-1, 0)]
     else:
-        cfgs = [0, 1, 2, 3] if op == 10 else range(6)
+        cfgs = [0, 1, 2, 3, 6, 7, 8] if op == 10 else range(9)
         for c in cfgs:
-            for ks in (8, 16, 24, 32, 48, 64):
+            for ks in (8, 16, 32, 48, 64):
                 out.append((c, ks, -1)); out.append((c, ks, 2))
     return out
 
