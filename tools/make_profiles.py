@@ -6,7 +6,7 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(n):
     n = re.sub(r'paac::', '', n)
-    m = re.match(r'void dmm_kernel<Geom<([0-9, ]+)>, (true|false), (\d), (\d), (\d), (\d), (\d), (\d), (\d), (\d+), (\d), (true|false), (\d)>', n)
+    m = re.search(r'dmm_kernel<Dmm<Geom<([0-9, ]+)>, (true|false), (\d), (\d), (\d), (\d), (\d), (\d), (\d), (\d+), (\d), (true|false), (\d)> ?>', n)
     if m:
         return 'dmm<G%s u8=%s ap%s bp%s T%sx%s W%s,%s,%s epi%s bias=%s pf%s>' % (
             m.group(1).replace(' ', ''), m.group(2)[0], m.group(3), m.group(4), m.group(5), m.group(6), m.group(7), m.group(8),
@@ -61,10 +61,11 @@ PATTERNS = [("conv1_fwd", "G84,84,4,20,20", "ap0"), ("conv1_wgrad", "G84,84,4,20
             ("conv3_dgrad", "G7,7,64,9,9", "ap0"), ("conv2_dgrad", "G9,9,64,10,10", "ap0")]
 meta = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
 n_act, n_train = meta["config"]["envs_per_gpu"], meta["config"]["envs_per_gpu"] * meta["config"]["t_max"]
+n_fwd = n_train + n_act       # the training forward carries the bootstrap rows
 fam = {}
 for name, gpat, ap in PATTERNS:
     ks = sorted([k for k in fe if gpat in k[0] and (" %s " % ap) in k[0]], key=lambda k: traffic["%s|%s" % k])
-    batches = [n_act, n_train] if len(ks) == 2 else ([n_train] if "grad" in name else [n_act])
+    batches = [n_act, n_fwd] if len(ks) == 2 else ([n_train] if "grad" in name else [n_act])
     for k, b in zip(ks, batches):
         fam["%s[batch=%d]" % (name, b)] = traffic["%s|%s" % k]
 json.dump({"workload": meta["config"]["workload"], "bytes_per_launch": fam,
