@@ -545,12 +545,23 @@ constexpr int NORM_BLOCKS = 256;
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float scale,
                                                     float* __restrict__ partials) {
+  // latency-bound (a few float4 per thread): every load of a pass is issued before the first one is consumed
+  constexpr int U = 8;
+  constexpr long STRIDE = (long)NORM_BLOCKS * 256;
   float acc = 0.f;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)NORM_BLOCKS * 256) {
-    float4 v = g4[i];
-    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  for (long i0 = blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * STRIDE) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * STRIDE;
+      v[u] = (i < n4) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float x = v[u].x * scale, y = v[u].y * scale, z = v[u].z * scale, w = v[u].w * scale;
+      acc += (x * x + y * y) + (z * z + w * w);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -568,6 +579,16 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
                                                       const float* __restrict__ lr_dev, float decay, float momentum,
                                                       float eps, float clip_norm, int clip_mode, float scale,
                                                       const float* __restrict__ partials, float* __restrict__ gnorm_out) {
+  // the streams do not depend on the norm: request them first, reduce the partials while they are in flight
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n4;
+  const long il = live ? i : 0;
+  float4 gv = reinterpret_cast<const float4*>(g)[il];
+  float4 m = reinterpret_cast<float4*>(ms)[il];
+  float4 mo = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (MOM) mo = reinterpret_cast<float4*>(mom)[il];
+  float4 v = reinterpret_cast<float4*>(var)[il];
+  const float lr = *lr_dev;
   // every block reduces the same 256 partials in the same order -> identical norm everywhere
   float acc = partials[threadIdx.x];
 #pragma unroll
@@ -585,15 +606,8 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
   }
   __syncthreads();
   const float f = s_factor * scale;
-  const float lr = *lr_dev;
   const float omd = 1.0f - decay;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  float4 gv = reinterpret_cast<const float4*>(g)[i];
-  float4 m = reinterpret_cast<float4*>(ms)[i];
-  float4 mo = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (MOM) mo = reinterpret_cast<float4*>(mom)[i];
-  float4 v = reinterpret_cast<float4*>(var)[i];
+  if (!live) return;
 #define PAAC_RMS(c)                                           \
   {                                                           \
     const float gg = gv.c * f;                                \
