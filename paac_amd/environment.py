@@ -9,6 +9,33 @@ returns (environment.py:66-71).
 import numpy as np
 
 
+def pil_nearest_lut(src, dst=84):
+    """Source index of every destination pixel under PIL's NEAREST resize, which is what
+    scipy.misc.imresize(img, (84, 84), interp='nearest') (atari_emulator.py:73) evaluates: the source position is
+    ACCUMULATED in double precision (xo += scale), not recomputed per pixel -- 160 -> 84 columns 52 and 73 land on
+    99 / 139."""
+    scale = src / float(dst)
+    xo = 0.0 + scale * 0.5
+    lut = np.empty(dst, dtype=np.int64)
+    for x in range(dst):
+        lut[x] = int(xo)
+        xo += scale
+    return lut
+
+
+_LUTS = {}
+
+
+def max_resize_84(frames):
+    """atari_emulator.py:69-75: element-wise max over the pooled screens [k,H,W], then nearest resize to 84x84 u8."""
+    frames = np.asarray(frames)
+    h, w = frames.shape[-2:]
+    if (h, w) not in _LUTS:
+        _LUTS[(h, w)] = (pil_nearest_lut(h), pil_nearest_lut(w))
+    rows, cols = _LUTS[(h, w)]
+    return np.amax(frames, axis=0)[rows][:, cols].astype(np.uint8)
+
+
 class BaseEnvironment(object):
     def get_initial_state(self):
         """Sets the environment to its initial state; returns uint8 [84,84,4]."""

@@ -20,6 +20,17 @@ class EnvironmentCreator(object):
     def __init__(self, args):
         game = getattr(args, "game", "pong")
         self.args = args
+        if getattr(args, "emulator", "synthetic") == "ale":
+            # environment_creator.py:8-14: the ROM decides the action count; one AtariEmulator per actor.  No device
+            # twin: these environments are stepped on the host (screens -> GPU with --device_preprocess true).
+            from . import atari_emulator
+            probe = atari_emulator._open_ale()
+            probe.loadROM(("%s/%s.bin" % (args.rom_path, game)).encode())
+            self.num_actions = len(probe.getMinimalActionSet())
+            self.create_environment = lambda i: atari_emulator.AtariEmulator(i, args)
+            self._device_twin = False
+            return
+        self._device_twin = True
         self.num_actions = int(getattr(args, "num_actions_override", 0) or GAME_NUM_ACTIONS.get(game, 6))
         # args.random_seed is set by train.get_network_and_environment_creator AFTER this constructor runs
         # (train.py:52-56), so it is read when an environment is created, like atari_emulator.py:18 does.
@@ -38,5 +49,7 @@ class EnvironmentCreator(object):
     @property
     def device_env_spec(self):
         """Device-batched twin of the same environments (PAACLearner uses it when present)."""
+        if not self._device_twin:
+            return None
         return dict(kind="synthetic", seed=self._seed(), terminal_threshold=terminal_threshold(self._terminal_p()),
                     raw_frames=self._raw())

@@ -17,9 +17,9 @@ import time
 import numpy as np
 import torch
 
-from . import hip_ops, parallel
+from . import hip_ops, logger_utils, parallel
 from .actor_learner import ActorLearner
-from .runners import EmulatorRunner, Runners
+from .runners import EmulatorRunner, RawEmulatorRunner, Runners
 
 
 class DeviceRollout(object):
@@ -208,6 +208,33 @@ class DeviceRollout(object):
         self.graph_b = None
 
 
+class DeviceObservations(object):
+    """Observations of host environments that emit raw screens, built on the GPU: the screen pairs travel through
+    pinned staging buffers, paac_preprocess_stack does max + nearest resize + history push for all environments in
+    one launch per slot (one slot per step; HISTORY slots for the environments that were just reset)."""
+
+    def __init__(self, n_envs, slots, dev):
+        self.staging = torch.empty((slots, n_envs, 2, hip_ops.RAW_H, hip_ops.RAW_W), dtype=torch.uint8).pin_memory()
+        self.mask_staging = torch.empty((slots, n_envs), dtype=torch.uint8).pin_memory()
+        self.d_raw = torch.empty((slots, n_envs, 2, hip_ops.RAW_H, hip_ops.RAW_W), dtype=torch.uint8, device=dev)
+        self.d_mask = torch.empty((slots, n_envs), dtype=torch.uint8, device=dev)
+        self.current = torch.zeros((n_envs, 84, 84, 4), dtype=torch.uint8, device=dev)
+
+    def update(self, raw, counts):
+        """raw u8 [N,slots,2,210,160], counts [N]: environment i pushes its first counts[i] slots."""
+        if tuple(raw.shape[2:]) != (2, hip_ops.RAW_H, hip_ops.RAW_W):
+            raise ValueError("device preprocessing expects %dx%d screens, got %s" %
+                             (hip_ops.RAW_H, hip_ops.RAW_W, tuple(raw.shape[3:])))
+        counts = np.asarray(counts).astype(np.int64)
+        for j in range(int(counts.max())):
+            self.staging[j].copy_(torch.from_numpy(raw[:, j]))
+            self.mask_staging[j].copy_(torch.from_numpy((counts > j).astype(np.uint8)))
+            self.d_raw[j].copy_(self.staging[j], non_blocking=True)
+            self.d_mask[j].copy_(self.mask_staging[j], non_blocking=True)
+            hip_ops.preprocess_stack(self.d_raw[j], self.current, self.current, push_mask=self.d_mask[j])
+        return self.current
+
+
 class PAACLearner(ActorLearner):
     def __init__(self, network_creator, environment_creator, args):
         super(PAACLearner, self).__init__(network_creator, environment_creator, args)
@@ -215,6 +242,23 @@ class PAACLearner(ActorLearner):
         self.args = args
         self.runners = None
         self.rollout = None
+        self.metrics = None
+
+    def _open_metrics(self):
+        """metrics.jsonl in the debugging folder (rank 0 only): what the reference sends to TensorBoard."""
+        if self.metrics is None and parallel.rank() == 0 and getattr(self.args, "metrics", True):
+            self.metrics = logger_utils.MetricsWriter(self.debugging_folder)
+        return self.metrics
+
+    def _progress_record(self, steps_per_s, steps_per_s_avg, last_ten):
+        if self.metrics is None:
+            return
+        loss = self.loss_dev.cpu().numpy()
+        self.metrics.write("progress", global_step=int(self.global_step), steps_per_s=float(steps_per_s),
+                           steps_per_s_avg=float(steps_per_s_avg), last_10_rewards_avg=float(last_ten),
+                           lr=float(self.lr_dev.item()), grad_norm=float(self.gnorm_dev.item()), loss=float(loss[0]),
+                           actor_loss=float(loss[1]), critic_loss=float(loss[2]), entropy=float(loss[3]))
+        self.metrics.flush()
 
     @staticmethod
     def choose_next_actions(network, num_actions, states, session):
@@ -271,6 +315,8 @@ class PAACLearner(ActorLearner):
         start_time = time.time()
         log_every = 2048 / self.emulator_counts            # paac.py:172 (float division, as upstream)
         steps_per_cycle = N * T * world
+        metrics = self._open_metrics()
+        episodes_seen = 0
         while self.global_step < self.max_global_steps:
             loop_start_time = time.time()
             self.rollout.run_cycle()
@@ -279,11 +325,17 @@ class PAACLearner(ActorLearner):
             if counter % log_every == 0:
                 self.rollout.synchronize()
                 curr_time = time.time()
-                _, eps = self.rollout.finished_episodes()
+                count, eps = self.rollout.finished_episodes()
                 last_ten = 0.0 if len(eps) < 1 else np.mean([r for r, _ in eps[-10:]])
                 logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), last 10 rewards avg {}"
                              .format(self.global_step, steps_per_cycle / (curr_time - loop_start_time),
                                      (self.global_step - global_step_start) / (curr_time - start_time), last_ten))
+                if metrics is not None:
+                    for r, l in eps[max(0, len(eps) - (count - episodes_seen)):]:     # new since the last drain
+                        metrics.write("episode", global_step=int(self.global_step), reward=float(r), length=int(l))
+                    episodes_seen = count
+                    self._progress_record(steps_per_cycle / (curr_time - loop_start_time),
+                                          (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
             self.save_vars()
         self.rollout.synchronize()
 
@@ -294,13 +346,30 @@ class PAACLearner(ActorLearner):
         counter = 0
         global_step_start = self.global_step
         total_rewards = []
-        variables = [(np.asarray([emulator.get_initial_state() for emulator in self.emulators], dtype=np.uint8)),
-                     (np.zeros(N, dtype=np.float32)),
-                     (np.asarray([False] * N, dtype=np.float32)),
-                     (np.zeros((N, A), dtype=np.float32))]
-        self.runners = Runners(EmulatorRunner, self.emulators, self.workers, variables)
-        self.runners.start()
-        shared_states, shared_rewards, shared_episode_over, shared_actions = self.runners.get_shared_variables()
+        raw_mode = bool(getattr(self.args, "device_preprocess", False))
+        if raw_mode:
+            # environments hand out raw screen pairs; observations are built on the GPU (DeviceObservations)
+            if not all(hasattr(e, "next_raw") and hasattr(e, "initial_raw") for e in self.emulators):
+                raise Exception("--device_preprocess needs environments with initial_raw() / next_raw()")
+            first = np.stack([emulator.initial_raw() for emulator in self.emulators]).astype(np.uint8)
+            variables = [first, np.full(N, first.shape[1], dtype=np.float32), np.zeros(N, dtype=np.float32),
+                         np.asarray([False] * N, dtype=np.float32), np.zeros((N, A), dtype=np.float32)]
+            self.runners = Runners(RawEmulatorRunner, self.emulators, self.workers, variables)
+            self.runners.start()
+            shared_raw, shared_counts, shared_rewards, shared_episode_over, shared_actions = \
+                self.runners.get_shared_variables()
+            observations = DeviceObservations(N, first.shape[1], dev)
+            observations.update(shared_raw, shared_counts)
+            current_states = lambda: observations.current
+        else:
+            variables = [(np.asarray([emulator.get_initial_state() for emulator in self.emulators], dtype=np.uint8)),
+                         (np.zeros(N, dtype=np.float32)),
+                         (np.asarray([False] * N, dtype=np.float32)),
+                         (np.zeros((N, A), dtype=np.float32))]
+            self.runners = Runners(EmulatorRunner, self.emulators, self.workers, variables)
+            self.runners.start()
+            shared_states, shared_rewards, shared_episode_over, shared_actions = self.runners.get_shared_variables()
+            current_states = lambda: torch.from_numpy(shared_states)
 
         emulator_steps = [0] * N
         total_episode_rewards = N * [0]
@@ -321,17 +390,20 @@ class PAACLearner(ActorLearner):
         params = self.network.params
         start_time = time.time()
         self.last_feed = None
+        metrics = self._open_metrics()
 
         while self.global_step < self.max_global_steps:
             loop_start_time = time.time()
             for t in range(T):
-                d_states[t].copy_(torch.from_numpy(shared_states))
+                d_states[t].copy_(current_states())
                 self.ctx.forward(params, d_states[t], probs=d_probs, values=d_values[t])
                 hip_ops.sample_mt(d_probs, mt_state, mt_scratch, d_actions[t])
                 idx = d_actions[t].cpu().numpy()
                 shared_actions[...] = np.eye(A, dtype=np.float32)[idx]
                 self.runners.update_environments()
                 self.runners.wait_updated()
+                if raw_mode:
+                    observations.update(shared_raw, shared_counts)
                 masks[t] = 1.0 - shared_episode_over.astype(np.float32)
                 for e, (actual_reward, episode_over) in enumerate(zip(shared_rewards, shared_episode_over)):
                     total_episode_rewards[e] += actual_reward
@@ -340,9 +412,12 @@ class PAACLearner(ActorLearner):
                     self.global_step += 1
                     if episode_over:
                         total_rewards.append(total_episode_rewards[e])
+                        if metrics is not None:                      # paac.py:130-135
+                            metrics.write("episode", global_step=int(self.global_step),
+                                          reward=float(total_episode_rewards[e]), length=int(emulator_steps[e]))
                         total_episode_rewards[e] = 0
                         emulator_steps[e] = 0
-            d_cur.copy_(torch.from_numpy(shared_states))
+            d_cur.copy_(current_states())
             self.ctx.forward(params, d_cur, values=d_vboot)
             d_rewards.copy_(torch.from_numpy(rewards))
             d_masks.copy_(torch.from_numpy(masks))
@@ -367,6 +442,8 @@ class PAACLearner(ActorLearner):
                 logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), last 10 rewards avg {}"
                              .format(self.global_step, T * N / (curr_time - loop_start_time),
                                      (self.global_step - global_step_start) / (curr_time - start_time), last_ten))
+                self._progress_record(T * N / (curr_time - loop_start_time),
+                                      (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
             self.save_vars()
         np.random.set_state(hip_ops.mt_state_to_numpy(mt_state))
 
@@ -377,3 +454,6 @@ class PAACLearner(ActorLearner):
             self.runners = None
         if self.rollout is not None:
             self.rollout.close()
+        if self.metrics is not None:
+            self.metrics.close()
+            self.metrics = None

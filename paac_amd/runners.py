@@ -32,7 +32,27 @@ def step_emulators(emulators, variables):
         overs[i] = episode_over
 
 
+def step_emulators_raw(emulators, variables):
+    """The same protocol for environments that hand out RAW screens (AtariEmulator.next_raw / initial_raw): slot 0 of
+    raw[i] is the step's screen pair and counts[i] == 1; after a terminal the environment is reset and its slots hold
+    the pairs that build the initial observation (counts[i] == number of slots).  The GPU turns them into
+    observations (paac_preprocess_stack)."""
+    raw, counts, rewards, overs, actions = variables
+    for i, (emulator, action) in enumerate(zip(emulators, actions)):
+        pair, reward, episode_over = emulator.next_raw(action)
+        if episode_over:
+            raw[i] = emulator.initial_raw()
+            counts[i] = raw.shape[1]
+        else:
+            raw[i, 0] = pair
+            counts[i] = 1
+        rewards[i] = reward
+        overs[i] = episode_over
+
+
 class EmulatorRunner(mp.Process):
+    step = staticmethod(step_emulators)
+
     def __init__(self, id, emulators, variables, queue, barrier):
         super(EmulatorRunner, self).__init__()
         self.id, self.emulators, self.variables, self.queue, self.barrier = id, emulators, variables, queue, barrier
@@ -43,14 +63,19 @@ class EmulatorRunner(mp.Process):
             instruction = self.queue.get()
             if instruction is None:
                 break
-            step_emulators(self.emulators, self.variables)
+            self.step(self.emulators, self.variables)
             self.barrier.put(True)
+
+
+class RawEmulatorRunner(EmulatorRunner):
+    step = staticmethod(step_emulators_raw)
 
 
 class Runners(object):
     def __init__(self, EmulatorRunner, emulators, workers, variables):
         self.emulators = list(emulators)
         self.workers = int(workers)
+        self.step = EmulatorRunner.step      # the runner class decides how a slice of environments is stepped
         self.variables = [self._get_shared(v) for v in variables]
         self.runners = []
         if self.workers > 0:
@@ -88,7 +113,7 @@ class Runners(object):
             for q in self.queues:
                 q.put(True)
         else:
-            step_emulators(self.emulators, self.variables)
+            self.step(self.emulators, self.variables)
 
     def wait_updated(self):
         if self.workers > 0:

@@ -23,7 +23,7 @@ Spec (all arithmetic uint32, wrapping):
 """
 import numpy as np
 
-from .environment import BaseEnvironment
+from .environment import BaseEnvironment, pil_nearest_lut
 
 M32 = np.uint64(0xFFFFFFFF)
 REWARD_TABLE = np.array([-2.0, 0.0, 0.0, 1.0, 3.0], dtype=np.float32)
@@ -66,18 +66,8 @@ def raw_frames_b(key):
     return words.astype("<u4").view(np.uint8).reshape(2, 210, 160)
 
 
-def _pil_nearest_lut(src, dst=84):
-    scale = src / float(dst)
-    xo = 0.0 + scale * 0.5
-    lut = np.empty(dst, dtype=np.int64)
-    for x in range(dst):
-        lut[x] = int(xo)
-        xo += scale
-    return lut
-
-
-ROW_LUT = _pil_nearest_lut(210)
-COL_LUT = _pil_nearest_lut(160)
+ROW_LUT = pil_nearest_lut(210)
+COL_LUT = pil_nearest_lut(160)
 
 
 class SyntheticEnvironment(BaseEnvironment):

@@ -5,13 +5,12 @@ Extra flags (not in the reference) are namespaced `--synthetic_*`, `--sampler`, 
 """
 import argparse
 import copy
-import json
 import logging
 import os
 import signal
 import sys
 
-from . import environment_creator
+from . import environment_creator, logger_utils
 from .paac import PAACLearner
 from .policy_v_network import NaturePolicyVNetwork, NIPSPolicyVNetwork
 
@@ -102,16 +101,12 @@ def get_arg_parser():
     parser.add_argument('--host_environments', default=False, type=bool_arg, help="Step BaseEnvironment plugins on the host even when a device twin exists", dest="host_environments")
     parser.add_argument('--synthetic_terminal_p', default=0.01, type=float, dest="synthetic_terminal_p")
     parser.add_argument('--synthetic_raw_frames', default=False, type=bool_arg, help="Synthetic envs emit two raw 210x160 frames per step (max + nearest resize + stack on the GPU)", dest="synthetic_raw_frames")
+    parser.add_argument('--emulator', default='synthetic', choices=['synthetic', 'ale'], help="Environments: the synthetic family of paac_amd/synthetic.py, or Atari through an installed Arcade Learning Environment (paac_amd/atari_emulator.py)", dest="emulator")
+    parser.add_argument('--device_preprocess', default=False, type=bool_arg, help="Host environments hand out raw 210x160 screen pairs; max + resize + frame history run on the GPU", dest="device_preprocess")
     return parser
 
 
-def save_args(args, folder, file_name='args.json'):
-    """logger_utils.py:15-20."""
-    d = {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, type(None)))}
-    if not os.path.exists(folder):
-        os.makedirs(folder)
-    with open(os.path.join(folder, file_name), 'w') as f:
-        return json.dump(d, f)
+save_args = logger_utils.save_args      # logger_utils.py:15-20
 
 
 if __name__ == '__main__':
