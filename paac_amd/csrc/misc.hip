@@ -137,7 +137,10 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   const int D = N * J;
   __shared__ float probs_s[LDSPATH ? 2 * MT_LDS_D : 1];   // N*A = D*A/(A-1) <= 2*D floats
   __shared__ uint32_t pos_s;
+  __shared__ int any_zero;       // some conditional probability is exactly 0 (the table chase needs none); later
+                                 // reused for the consumed-draw count
   uint32_t pos;
+  if (tid == 0) any_zero = 0;    // ordered before phase 1 by the barrier below (LDSPATH) / after phase 2's copy
   if constexpr (LDSPATH) {
     // ONE memory round trip: the 625 state words and the N*A probabilities are all requested before anything
     // is consumed (unrolled, clamped indices), then parked in LDS.
@@ -169,7 +172,9 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     for (int j = 0; j < J; ++j) {
       const float p32 = pr[(long)e * A + j] - 5.9604644775390625e-08f;  // float32 arithmetic, paac.py:42
       const double p = (double)p32;
-      pj_buf[(long)e * J + j] = p / remaining;
+      const double cond = p / remaining;
+      pj_buf[(long)e * J + j] = cond;
+      if (LDSPATH && cond == 0.0) any_zero = 1;
       remaining -= p;
     }
   }
@@ -203,17 +208,11 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   // every reachable (e, o) in parallel (o <= e*J), then one lane chases the table: N dependent LDS byte reads
   // instead of N ballot/popcount/compare rounds.
   __shared__ unsigned char jh_tab[LDSPATH ? MT_TAB_MAX : 1];
-  __shared__ int any_zero;
   bool chased = false;
   if constexpr (LDSPATH) {
     const long tab_entries = (long)N + (long)J * N * (N - 1) / 2;
     if (tab_entries <= MT_TAB_MAX && N <= 256) {
-      if (tid == 0) any_zero = 0;
-      __syncthreads();
-      for (int d = tid; d < D; d += 256)
-        if (pj_buf[d] == 0.0) any_zero = 1;
-      __syncthreads();
-      if (!any_zero) {
+      if (!any_zero) {     // set in phase 1, visible since the barrier after phase 3
         const int tpe = 256 / N;                       // threads per env
         const int e = tid / tpe, k = tid - e * tpe;
         if (e < N) {
