@@ -4,6 +4,18 @@
 
 namespace paac {
 
+#ifdef PAAC_DMM_STAMPS
+__device__ unsigned long long* g_misc_stamps = nullptr;   // diagnostic build: phase stamps of the sampler workgroup
+#define MISC_STAMP(i)                                                                       \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (g_misc_stamps && threadIdx.x == 0) g_misc_stamps[(i)] = (unsigned long long)clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#else
+#define MISC_STAMP(i)
+#endif
+
 // =============================================================================================
 // n-step returns (paac.py:140-149), fp64 scan like the reference's numpy buffers.
 struct CycleTick {          // optional bookkeeping folded into the returns kernel (one launch instead of three)
@@ -126,6 +138,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
                                                double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
                                                int32_t* __restrict__ actions, int32_t* act_lds) {
+  MISC_STAMP(0);
   __shared__ double pj_s[LDSPATH ? MT_LDS_D : 1];
   __shared__ double u_s[LDSPATH ? MT_LDS_D : 1];
   __shared__ uint32_t blocks_s[LDSPATH ? MT_LDS_BLK * 624 : 1];
@@ -164,20 +177,23 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   } else {
     pos = mt_state[624];
   }
+  MISC_STAMP(1);
   const float* pr = LDSPATH ? probs_s : probs;
   const int nblk = (int)((pos + 2u * (uint32_t)D) / 624u) + 1;
-  // phase 1: per-env conditional probabilities p_j / remaining_j (sequential fp64 subtraction order)
-  for (int e = tid; e < N; e += 256) {
+  // phase 1: conditional probabilities p_j / remaining_j, one (env, category) per thread: the running
+  // `remaining` is rebuilt with the reference's sequential fp64 subtraction order (cheap), so that only ONE fp64
+  // division sits on each thread's critical path instead of J in a row
+  for (int d = tid; d < D; d += 256) {
+    const int e = d / J, j = d - e * J;
     double remaining = 1.0;
-    for (int j = 0; j < J; ++j) {
-      const float p32 = pr[(long)e * A + j] - 5.9604644775390625e-08f;  // float32 arithmetic, paac.py:42
-      const double p = (double)p32;
-      const double cond = p / remaining;
-      pj_buf[(long)e * J + j] = cond;
-      if (LDSPATH && cond == 0.0) any_zero = 1;
-      remaining -= p;
-    }
+    for (int i = 0; i < j; ++i)
+      remaining -= (double)(pr[(long)e * A + i] - 5.9604644775390625e-08f);   // float32 arithmetic, paac.py:42
+    const double p = (double)(pr[(long)e * A + j] - 5.9604644775390625e-08f);
+    const double cond = p / remaining;
+    pj_buf[d] = cond;
+    if (LDSPATH && cond == 0.0) any_zero = 1;
   }
+  MISC_STAMP(2);
   // phase 2: successive MT19937 state blocks
   if constexpr (!LDSPATH) {
     for (int i = tid; i < 624; i += 256) blocks[i] = mt_state[i];
@@ -195,14 +211,16 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     if (tid == 0) nw[623] = nw[396] ^ mt_mix(o[623], nw[0]);
     __syncthreads();
   }
+  MISC_STAMP(3);
   // phase 3: the 53-bit doubles numpy would draw, in stream order
   for (int d = tid; d < D; d += 256) {
     const uint32_t q = pos + 2u * (uint32_t)d;
     const uint32_t a = mt_temper(blocks[q]) >> 5;
     const uint32_t b = mt_temper(blocks[q + 1]) >> 6;
-    u_buf[d] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    u_buf[d] = ((double)a * 67108864.0 + (double)b) * 1.1102230246251565404e-16;   // * 2^-53, exact
   }
   __syncthreads();
+  MISC_STAMP(4);
   // phase 4a (fast path): when every conditional probability is non-zero the stream offset after env e is
   // o + min(jh+1, J) with jh = first category hit when env e starts drawing at offset o.  jh is tabulated for
   // every reachable (e, o) in parallel (o <= e*J), then one lane chases the table: N dependent LDS byte reads
@@ -213,35 +231,69 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     const long tab_entries = (long)N + (long)J * N * (N - 1) / 2;
     if (tab_entries <= MT_TAB_MAX && N <= 256) {
       if (!any_zero) {     // set in phase 1, visible since the barrier after phase 3
-        const int tpe = 256 / N;                       // threads per env
-        const int e = tid / tpe, k = tid - e * tpe;
-        if (e < N) {
-          const int base = e + J * e * (e - 1) / 2;    // sum_{e' < e} (e' J + 1)
-          for (int o = k; o <= e * J; o += tpe) {
-            int jh = J;
-            for (int j = J - 1; j >= 0; --j) {
-              const double pj = pj_buf[e * J + j];
-              const double U = u_buf[o + j < D ? o + j : D - 1];
-              bool hit;
-              if (pj <= 0.5) {
-                hit = U > 1.0 - pj;
-              } else {
-                const double q = 1.0 - pj;
-                hit = !(U > 1.0 - q);
-              }
-              if (hit) jh = j;
+        // Table fill: environment e has e*J + 1 reachable offsets, so e is paired with N-1-e -- every pair has
+        // (N-1) J + 2 entries -- and each pair is filled by one 16-thread group.  An entry costs J LDS reads of the
+        // draws (the thresholds sit in registers for J <= JR), all issued before the compares.
+        constexpr int JR = 8;
+        const int grp = tid >> 4, k = tid & 15;
+        const int npairs = (N + 1) / 2;
+        for (int pe = grp; pe < npairs; pe += 16) {
+          const int ea = pe, eb = N - 1 - pe;
+          const int cnt_a = ea * J + 1, cnt_b = (eb != ea) ? eb * J + 1 : 0;
+          const int base_a = ea + J * ea * (ea - 1) / 2, base_b = eb + J * eb * (eb - 1) / 2;
+          double thr_a[JR], thr_b[JR];
+          bool inv_a[JR], inv_b[JR];
+          auto threshold = [&](int e, int j, double& thr, bool& inv) {   // hit(U) == ((U > thr) != inv)
+            const double pj = pj_buf[e * J + j];
+            inv = !(pj <= 0.5);
+            thr = inv ? 1.0 - (1.0 - pj) : 1.0 - pj;
+          };
+#pragma unroll
+          for (int j = 0; j < JR; ++j) {
+            if (j < J) {
+              threshold(ea, j, thr_a[j], inv_a[j]);
+              threshold(eb, j, thr_b[j], inv_b[j]);
             }
-            jh_tab[base + o] = (unsigned char)jh;
+          }
+          for (int c = k; c < cnt_a + cnt_b; c += 16) {
+            const bool first = c < cnt_a;
+            const int e = first ? ea : eb;
+            const int o = first ? c : c - cnt_a;
+            int jh = J;
+            if (J <= JR) {
+              double U[JR];
+#pragma unroll
+              for (int j = 0; j < JR; ++j) U[j] = (j < J) ? u_buf[o + j < D ? o + j : D - 1] : 0.0;
+#pragma unroll
+              for (int j = JR - 1; j >= 0; --j) {
+                if (j < J) {
+                  const double thr = first ? thr_a[j] : thr_b[j];
+                  const bool inv = first ? inv_a[j] : inv_b[j];
+                  if ((U[j] > thr) != inv) jh = j;
+                }
+              }
+            } else {
+              for (int j = J - 1; j >= 0; --j) {
+                double thr;
+                bool inv;
+                threshold(e, j, thr, inv);
+                if ((u_buf[o + j < D ? o + j : D - 1] > thr) != inv) jh = j;
+              }
+            }
+            jh_tab[(first ? base_a : base_b) + o] = (unsigned char)jh;
           }
         }
         __syncthreads();
+        MISC_STAMP(5);
         if (tid == 0) {
-          int o = 0;
+          int o = 0, base = 0, ej = 0;               // base(e) = e + J e (e-1)/2, ej = e J
           for (int e = 0; e < N; ++e) {
-            const int jh = jh_tab[e + J * e * (e - 1) / 2 + o];
+            const int jh = jh_tab[base + o];
             actions[e] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
             if (act_lds) act_lds[e] = jh;
             o += (jh + 1 < J) ? jh + 1 : J;
+            base += ej + 1;
+            ej += J;
           }
           jh_tab[0] = 0;
           any_zero = o;                                 // reuse as the consumed-draw count
@@ -251,6 +303,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
       }
     }
   }
+  MISC_STAMP(6);
   // phase 4b: one wavefront walks the envs in index order; lane j owns category j
   if (tid < 64) {
     const int lane = tid;
@@ -413,19 +466,19 @@ struct FinishedRing {
   int32_t len[4096];
 };
 
-// Per-env bookkeeping shared by both paths: emulator_runner.py:30-31 + paac.py:119-138.
-__device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_t* actions, uint32_t thresh,
-                                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
-                                               FinishedRing* fin) {
+// Per-env bookkeeping shared by both paths: emulator_runner.py:30-31 + paac.py:119-138.  ep_reward0 / ep_len0 = the
+// running totals before this step (callers that have something to wait for load them early).
+__device__ __forceinline__ bool synth_bookkeep_with(uint32_t key, int e, int act, uint32_t thresh, float ep_reward0,
+                                                    int32_t ep_len0, float* rewards_out, float* masks_out,
+                                                    float* ep_reward, int32_t* ep_len, FinishedRing* fin) {
   const float table[5] = {-2.f, 0.f, 0.f, 1.f, 3.f};
   const uint32_t hr = lowbias32(key ^ 0xA511E9B3u);
-  const int act = actions ? actions[e] : 0;
   const float r = table[(hr % 5u + (uint32_t)act) % 5u];
   const bool term = lowbias32(key ^ 0x3C6EF372u) < thresh;
   rewards_out[e] = fminf(fmaxf(r, -1.f), 1.f);   // actor_learner.py:95-101
   masks_out[e] = term ? 0.f : 1.f;               // paac.py:119
-  const float tot = ep_reward[e] + r;
-  const int len = ep_len[e] + 1;
+  const float tot = ep_reward0 + r;
+  const int len = ep_len0 + 1;
   if (term) {
     if (fin) {
       const int slot = atomicAdd(&fin->count, 1) & 4095;
@@ -439,6 +492,12 @@ __device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_
     ep_len[e] = len;
   }
   return term;
+}
+__device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_t* actions, uint32_t thresh,
+                                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
+                                               FinishedRing* fin) {
+  return synth_bookkeep_with(key, e, actions ? actions[e] : 0, thresh, ep_reward[e], ep_len[e], rewards_out, masks_out,
+                             ep_reward, ep_len, fin);
 }
 
 // Path A: one new 84x84 plane per step.  grid (N, 7), 256 threads; one dword (pixel x 4 channels) per thread-iteration.
@@ -490,12 +549,21 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   if (blockIdx.x == 0) {
     __shared__ int32_t act_s[MT_LDS_D];
+    // the running episode totals do not depend on the sampler: request them before it (first 256 environments)
+    const int e0 = threadIdx.x < N ? threadIdx.x : 0;
+    const float ep_reward0 = ep_reward[e0];
+    const int32_t ep_len0 = ep_len[e0];
     sample_mt_body<true>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);
     __syncthreads();
+    MISC_STAMP(7);
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
-      synth_bookkeep(key, e, act_s, thresh, rewards_out, masks_out, ep_reward, ep_len, fin);
+      if (e < 256)
+        synth_bookkeep_with(key, e, act_s[e], thresh, ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
+      else
+        synth_bookkeep(key, e, act_s, thresh, rewards_out, masks_out, ep_reward, ep_len, fin);
     }
+    MISC_STAMP(8);
     return;
   }
   const int e = (blockIdx.x - 1) / PRE_BANDS;
@@ -629,6 +697,10 @@ using namespace paac;
 // =============================================================================================
 // C-ABI wrappers
 extern "C" {
+
+#ifdef PAAC_DMM_STAMPS
+void paac_debug_set_misc_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_misc_stamps), &p, sizeof(p)); }
+#endif
 
 int paac_nstep_returns(const float* v_boot, const float* rewards, const float* masks, const float* values, int T, int N,
                        double gamma, float* y, float* adv, paac_stream_t stream) {

@@ -1,0 +1,36 @@
+"""Diagnostic (stamped build only): phases of the sampler workgroup of the fused sampler + env-step launch.
+PAAC_HIP_LIB=.../libpaac_hip_stamps.so python tools/probe_sampler.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from paac_amd import hip_ops, _lib
+from paac_amd.synthetic import terminal_threshold
+lib = _lib.load()
+lib.paac_debug_set_misc_stamps.argtypes = [ctypes.c_void_p]
+N, A = int(os.environ.get("PROBE_N", "32")), int(os.environ.get("PROBE_A", "4"))
+dev = torch.device("cuda", 0)
+stamps = torch.zeros(16, dtype=torch.int64, device=dev)
+lib.paac_debug_set_misc_stamps(ctypes.c_void_p(stamps.data_ptr()))
+probs = torch.softmax(torch.randn(N, A, device=dev), dim=1)
+mt = hip_ops.mt_state_from_numpy(np.random.RandomState(1).get_state(), dev)
+act = torch.zeros(N, dtype=torch.int32, device=dev)
+s0 = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device=dev); s1 = torch.zeros_like(s0)
+rew = torch.zeros(N, device=dev); msk = torch.zeros(N, device=dev); epr = torch.zeros(N, device=dev)
+epl = torch.zeros(N, dtype=torch.int32, device=dev); fin = torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device=dev)
+tick = torch.zeros(1, dtype=torch.int64, device=dev)
+names = ["entry->loads landed", "phase 1 (cond. probabilities)", "phase 2 (state blocks)", "phase 3 (doubles)",
+         "table fill", "chase", "write-back", "bookkeeping"]
+acc = np.zeros(8)
+reps = 50
+for r in range(reps + 5):
+    probs = torch.softmax(torch.randn(N, A, device=dev), dim=1)    # cold-ish probabilities each time
+    torch.cuda.synchronize()
+    hip_ops.sample_mt_synth_step(probs, mt, act, 3, 0, terminal_threshold(0.01), tick, 0, s0, s1, rew, msk, epr, epl, fin)
+    torch.cuda.synchronize()
+    st = stamps.cpu().numpy().astype(np.float64)
+    if r >= 5:
+        acc += np.diff(st[:9])
+for n, v in zip(names, acc / reps):
+    print("%-32s %8.0f cycles" % (n, v))
+print("%-32s %8.0f cycles" % ("total (entry -> end)", acc.sum() / reps))
