@@ -228,19 +228,20 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   __shared__ unsigned char jh_tab[LDSPATH ? MT_TAB_MAX : 1];
   bool chased = false;
   if constexpr (LDSPATH) {
-    const long tab_entries = (long)N + (long)J * N * (N - 1) / 2;
+    // env e can only start at offsets e .. e J (every earlier env drew between 1 and J doubles)
+    const long tab_entries = (long)N + (long)(J - 1) * N * (N - 1) / 2;
     if (tab_entries <= MT_TAB_MAX && N <= 256) {
       if (!any_zero) {     // set in phase 1, visible since the barrier after phase 3
-        // Table fill: environment e has e*J + 1 reachable offsets, so e is paired with N-1-e -- every pair has
-        // (N-1) J + 2 entries -- and each pair is filled by one 16-thread group.  An entry costs J LDS reads of the
+        // Table fill: environment e has e (J-1) + 1 reachable offsets, so e is paired with N-1-e -- every pair has
+        // (N-1)(J-1) + 2 entries -- and each pair is filled by one 16-thread group.  An entry costs J LDS reads of the
         // draws (the thresholds sit in registers for J <= JR), all issued before the compares.
         constexpr int JR = 8;
         const int grp = tid >> 4, k = tid & 15;
         const int npairs = (N + 1) / 2;
         for (int pe = grp; pe < npairs; pe += 16) {
           const int ea = pe, eb = N - 1 - pe;
-          const int cnt_a = ea * J + 1, cnt_b = (eb != ea) ? eb * J + 1 : 0;
-          const int base_a = ea + J * ea * (ea - 1) / 2, base_b = eb + J * eb * (eb - 1) / 2;
+          const int cnt_a = ea * (J - 1) + 1, cnt_b = (eb != ea) ? eb * (J - 1) + 1 : 0;
+          const int base_a = ea + (J - 1) * ea * (ea - 1) / 2, base_b = eb + (J - 1) * eb * (eb - 1) / 2;
           double thr_a[JR], thr_b[JR];
           bool inv_a[JR], inv_b[JR];
           auto threshold = [&](int e, int j, double& thr, bool& inv) {   // hit(U) == ((U > thr) != inv)
@@ -258,7 +259,8 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
           for (int c = k; c < cnt_a + cnt_b; c += 16) {
             const bool first = c < cnt_a;
             const int e = first ? ea : eb;
-            const int o = first ? c : c - cnt_a;
+            const int idx = first ? c : c - cnt_a;   // table slot of the pair member
+            const int o = e + idx;                   // stream offset it stands for
             int jh = J;
             if (J <= JR) {
               double U[JR];
@@ -280,20 +282,20 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
                 if ((u_buf[o + j < D ? o + j : D - 1] > thr) != inv) jh = j;
               }
             }
-            jh_tab[(first ? base_a : base_b) + o] = (unsigned char)jh;
+            jh_tab[(first ? base_a : base_b) + idx] = (unsigned char)jh;
           }
         }
         __syncthreads();
         MISC_STAMP(5);
         if (tid == 0) {
-          int o = 0, base = 0, ej = 0;               // base(e) = e + J e (e-1)/2, ej = e J
+          int o = 0, base = 0, ej = 0;               // base(e) - e = (J-1) e (e-1)/2, ej = e (J-1)
           for (int e = 0; e < N; ++e) {
-            const int jh = jh_tab[base + o];
+            const int jh = jh_tab[base + o];         // slot base(e) + (o - e)
             actions[e] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
             if (act_lds) act_lds[e] = jh;
             o += (jh + 1 < J) ? jh + 1 : J;
-            base += ej + 1;
-            ej += J;
+            base += ej;
+            ej += J - 1;
           }
           jh_tab[0] = 0;
           any_zero = o;                                 // reuse as the consumed-draw count
