@@ -31,29 +31,53 @@ struct CycleTick {          // optional bookkeeping folded into the returns kern
 __global__ void nstep_returns_kernel(const float* __restrict__ v_boot, const float* __restrict__ rewards,
                                      const float* __restrict__ masks, const float* __restrict__ values, int T, int N,
                                      double gamma, float* __restrict__ y, float* __restrict__ adv, const CycleTick ct) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e == 0) {
-    if (ct.global_step) {
-      const int64_t step = *ct.global_step + ct.step_inc;
-      *ct.global_step = step;
-      double lr = 0.0;
-      if (step <= ct.anneal) lr = ct.lr0 - ((double)step * ct.lr0 / (double)ct.anneal);
-      *ct.lr_out = (float)lr;
+  // 128 threads: wave 0 scans 64 environments, wave 1 of workgroup 0 does the cycle bookkeeping -- its
+  // read-modify-write round trip runs beside the scan's instead of in front of it
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (threadIdx.x >= 64) {
+    if (blockIdx.x == 0 && threadIdx.x == 64) {
+      if (ct.global_step) {
+        const int64_t step = *ct.global_step + ct.step_inc;
+        *ct.global_step = step;
+        double lr = 0.0;
+        if (step <= ct.anneal) lr = ct.lr0 - ((double)step * ct.lr0 / (double)ct.anneal);
+        *ct.lr_out = (float)lr;
+      }
+      if (ct.tick) *ct.tick += ct.tick_inc;
     }
-    if (ct.tick) *ct.tick += ct.tick_inc;
+    return;
   }
   if (e >= N) return;
   // paac.py:146-147 as numpy evaluates it: estimated_return starts as the FLOAT32 network output, so the first
   // `gamma * estimated_return` is a float32 product (python float x float32 array -> float32, in numpy 1.x
   // and 2.x alike); it is promoted to float64 by `* masks[t]` and stays float64 afterwards.  Explicit
   // round-to-nearest mul/add (no FMA contraction) keep the scan bit-identical to numpy's.
+  // The scan is serial in t but its inputs are not: each chunk of CH steps is requested at once (one memory round
+  // trip per chunk instead of one per step -- at t_max = 5 the whole kernel is a single round trip).
+  constexpr int CH = 8;
+  const float vb = v_boot[e];
   double R = 0.0;
-  for (int t = T - 1; t >= 0; --t) {
-    const long i = (long)t * N + e;
-    const double prod = (t == T - 1) ? (double)__fmul_rn((float)gamma, v_boot[e]) : __dmul_rn(gamma, R);
-    R = __dadd_rn((double)rewards[i], __dmul_rn(prod, (double)masks[i]));
-    y[i] = (float)R;
-    adv[i] = (float)__dsub_rn(R, (double)values[i]);
+  for (int t0 = T - 1; t0 >= 0; t0 -= CH) {
+    float r[CH], m[CH], v[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int t = t0 - u;
+      const long i = (long)(t >= 0 ? t : 0) * N + e;
+      r[u] = rewards[i];
+      m[u] = masks[i];
+      v[u] = values[i];
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int t = t0 - u;
+      if (t >= 0) {
+        const long i = (long)t * N + e;
+        const double prod = (t == T - 1) ? (double)__fmul_rn((float)gamma, vb) : __dmul_rn(gamma, R);
+        R = __dadd_rn((double)r[u], __dmul_rn(prod, (double)m[u]));
+        y[i] = (float)R;
+        adv[i] = (float)__dsub_rn(R, (double)v[u]);
+      }
+    }
   }
 }
 
@@ -640,6 +664,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+constexpr int RMS_U = 4;   // float4 per thread and array in rmsprop_kernel
+
 // MOM = false: momentum == 0 (the reference's setting, actor_learner.py:31-34): the momentum slot is written (it
 // is checkpointed as OptimizerVariables_1) but not read.
 template <bool MOM>
@@ -648,15 +674,20 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
                                                       const float* __restrict__ lr_dev, float decay, float momentum,
                                                       float eps, float clip_norm, int clip_mode, float scale,
                                                       const float* __restrict__ partials, float* __restrict__ gnorm_out) {
-  // the streams do not depend on the norm: request them first, reduce the partials while they are in flight
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < n4;
-  const long il = live ? i : 0;
-  float4 gv = reinterpret_cast<const float4*>(g)[il];
-  float4 m = reinterpret_cast<float4*>(ms)[il];
-  float4 mo = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (MOM) mo = reinterpret_cast<float4*>(mom)[il];
-  float4 v = reinterpret_cast<float4*>(var)[il];
+  // the streams do not depend on the norm: request them first (RMS_U float4 per thread and array), reduce the
+  // partials while they are in flight
+  const long i0 = (long)blockIdx.x * (256 * RMS_U) + threadIdx.x;
+  float4 gv[RMS_U], m[RMS_U], mo[RMS_U], v[RMS_U];
+#pragma unroll
+  for (int u = 0; u < RMS_U; ++u) {
+    const long i = i0 + u * 256;
+    const long il = i < n4 ? i : 0;
+    gv[u] = reinterpret_cast<const float4*>(g)[il];
+    m[u] = reinterpret_cast<float4*>(ms)[il];
+    mo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MOM) mo[u] = reinterpret_cast<float4*>(mom)[il];
+    v[u] = reinterpret_cast<float4*>(var)[il];
+  }
   const float lr = *lr_dev;
   // every block reduces the same 256 partials in the same order -> identical norm everywhere
   float acc = partials[threadIdx.x];
@@ -676,20 +707,25 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
   __syncthreads();
   const float f = s_factor * scale;
   const float omd = 1.0f - decay;
-  if (!live) return;
-#define PAAC_RMS(c)                                           \
-  {                                                           \
-    const float gg = gv.c * f;                                \
-    m.c = m.c + (gg * gg - m.c) * omd;                        \
-    const float step = lr * gg / sqrtf(m.c + eps);            \
-    mo.c = MOM ? momentum * mo.c + step : step;               \
-    v.c = v.c - mo.c;                                         \
+#define PAAC_RMS(c)                                              \
+  {                                                              \
+    const float gg = gv[u].c * f;                                \
+    m[u].c = m[u].c + (gg * gg - m[u].c) * omd;                  \
+    const float step = lr * gg / sqrtf(m[u].c + eps);            \
+    mo[u].c = MOM ? momentum * mo[u].c + step : step;            \
+    v[u].c = v[u].c - mo[u].c;                                   \
   }
-  PAAC_RMS(x) PAAC_RMS(y) PAAC_RMS(z) PAAC_RMS(w)
+#pragma unroll
+  for (int u = 0; u < RMS_U; ++u) {
+    const long i = i0 + u * 256;
+    if (i < n4) {
+      PAAC_RMS(x) PAAC_RMS(y) PAAC_RMS(z) PAAC_RMS(w)
+      reinterpret_cast<float4*>(ms)[i] = m[u];
+      reinterpret_cast<float4*>(mom)[i] = mo[u];
+      reinterpret_cast<float4*>(var)[i] = v[u];
+    }
+  }
 #undef PAAC_RMS
-  reinterpret_cast<float4*>(ms)[i] = m;
-  reinterpret_cast<float4*>(mom)[i] = mo;
-  reinterpret_cast<float4*>(var)[i] = v;
 }
 
 }  // namespace paac
@@ -709,7 +745,7 @@ int paac_nstep_returns(const float* v_boot, const float* rewards, const float* m
   PAAC_REQUIRE(T > 0 && N > 0, "paac_nstep_returns: T=%d N=%d", T, N);
   CycleTick ct;
   memset(&ct, 0, sizeof(ct));
-  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, v_boot, rewards, masks,
+  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(128), 0, (hipStream_t)stream, v_boot, rewards, masks,
                      values, T, N, gamma, y, adv, ct);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -724,7 +760,7 @@ int paac_nstep_returns_tick(const float* v_boot, const float* rewards, const flo
   CycleTick ct;
   ct.global_step = global_step_dev; ct.step_inc = increment; ct.lr0 = initial_lr; ct.anneal = lr_annealing_steps;
   ct.lr_out = lr_out_dev; ct.tick = tick_dev; ct.tick_inc = tick_inc;
-  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, v_boot, rewards, masks,
+  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(128), 0, (hipStream_t)stream, v_boot, rewards, masks,
                      values, T, N, gamma, y, adv, ct);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -878,10 +914,10 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   const long n4 = n / 4;
   launch_k(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), s, PROF_FIRST, grad, n4, grad_scale, ctx->partials);
   if (momentum != 0.f)
-    launch_k(rmsprop_kernel<true>, dim3((n4 + 255) / 256), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
+    launch_k(rmsprop_kernel<true>, dim3((n4 + 256 * RMS_U - 1) / (256 * RMS_U)), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
              decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
   else
-    launch_k(rmsprop_kernel<false>, dim3((n4 + 255) / 256), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
+    launch_k(rmsprop_kernel<false>, dim3((n4 + 256 * RMS_U - 1) / (256 * RMS_U)), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
              decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
