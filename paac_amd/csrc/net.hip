@@ -204,7 +204,7 @@ static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-K slab reduction into the flat gradient (deterministic: fixed summation order, 8 loads in flight).
+// Split-K slab reduction into the flat gradient (deterministic: fixed summation order).
 struct FinalizeSeg {
   const float* src;  // first slab
   float* dst;
@@ -216,21 +216,34 @@ struct FinalizeArgs {
   FinalizeSeg seg[8];
   int nseg;
 };
+// FIN_LANES adjacent lanes share one output float4: lane r sums slabs r, r + FIN_LANES, ... (up to 8 loads, all in
+// flight at once: one memory round trip for up to 64 slabs), then the lanes' partial sums are combined by a fixed
+// xor tree -- the order of the additions never changes from run to run.
+constexpr int FIN_LANES = 8;
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinalizeArgs a) {
   const FinalizeSeg sg = a.seg[blockIdx.y];
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= sg.count) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int r = gid % FIN_LANES;
+  const int i = (gid / FIN_LANES) * 4;
+  const bool live = i < sg.count;     // whole lane groups are live or not: the shuffles below stay inside a group
   f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < sg.splits; s0 += 8) {
+  for (int s0 = r; s0 < sg.splits; s0 += 8 * FIN_LANES) {
     f32x4 t[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      t[u] = (s0 + u < sg.splits) ? *reinterpret_cast<const f32x4*>(sg.src + (long)(s0 + u) * sg.stride + i)
-                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 8; ++u) {
+      const int sp = s0 + u * FIN_LANES;
+      t[u] = (live && sp < sg.splits) ? *reinterpret_cast<const f32x4*>(sg.src + (long)sp * sg.stride + i)
+                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += t[u];
   }
-  *reinterpret_cast<f32x4*>(sg.dst + i) = v;
+#pragma unroll
+  for (int off = 1; off < FIN_LANES; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], off, 64);
+  }
+  if (live && r == 0) *reinterpret_cast<f32x4*>(sg.dst + i) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,7 +414,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     ProfScope ps(ctx, F_GRAD_FINALIZE, batch, s);
     int maxcount = 0;
     for (int i = 0; i < fin.nseg; ++i) maxcount = fin.seg[i].count > maxcount ? fin.seg[i].count : maxcount;
-    launch_k(grad_finalize_kernel, dim3((maxcount / 4 + 255) / 256, fin.nseg), dim3(256), s, PROF_WHOLE, fin);
+    launch_k(grad_finalize_kernel, dim3((maxcount / 4 * FIN_LANES + 255) / 256, fin.nseg), dim3(256), s, PROF_WHOLE, fin);
   }
   return 0;
 }
