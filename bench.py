@@ -86,12 +86,21 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    # Rehearsal knob for a one-GPU box: PAAC_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges gradients
+    # over gloo, so the N>1 code path (barriers, phased all-reduce, max over ranks) can be exercised without N GPUs.
+    # Never set by the driver; the numbers of such a run are meaningless.
+    rehearsal = os.environ.get("PAAC_BENCH_REHEARSAL", "") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from paac_amd import train
     from paac_amd.paac import DeviceRollout, PAACLearner
@@ -137,10 +146,11 @@ def main():
 
     roofline = None
     kernels = None
-    if rank == 0 and not a.no_roofline:
+    per = {}
+    if not a.no_roofline:
+        # every rank runs the event-timed pass (with N > 1 each cycle contains collectives); rank 0 reports
         learner.ctx.prof_enable(True)
         ro.use_graph = False
-        per = {}
         steps_done = 0
         # Eager launches are host-bound (~7 us per ctypes call): keep the GPU busy with a ~1 ms memset train while
         # the host enqueues the next cycle, so the kernels then run back to back and each event pair brackets GPU
@@ -161,6 +171,8 @@ def main():
             steps_done += chunk
         learner.ctx.prof_enable(False)
         ro.use_graph = not a.no_graph
+        del blocker
+    if rank == 0 and per:
         P = learner.network.layout["total_unpadded"]
         arch = "NIPS" if a.arch == "NIPS" else "NATURE"
         kernels = []
@@ -220,7 +232,7 @@ def main():
                                       "synthetic 84x84x4 u8 frames generated on device",
                                       a.sampler, "hipGraph replay" if not a.no_graph else "eager launches"),
                        "envs_per_gpu": N, "t_max": T, "global_envs": N * world,
-                       "parallelism": "env-sharded dp%d, one RCCL all-reduce of the flat gradient per update" % world},
+                       "parallelism": "env-sharded dp%d, RCCL sum all-reduce of the flat gradient per update (fc/heads part overlapped with the conv backward)" % world},
             "finite_params": finite,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }

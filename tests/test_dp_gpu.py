@@ -73,3 +73,23 @@ def test_two_ranks_track_single_process(tmp_path):
             continue
         assert np.array_equal(r0[k], r1[k]), "replicated weights diverged: %s" % k
         assert np.abs(r0[k] - one[k]).max() < 2e-5, k
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's own N > 1 path (torch.distributed.run, barriers, phased gradient exchange in the graph replay AND in
+    the event-timed pass, max over ranks, one JSON line from rank 0) rehearsed with two ranks on this one GPU over
+    gloo (PAAC_BENCH_REHEARSAL=1).  A rank-0-only pass with collectives in it would hang here."""
+    import json
+    import subprocess
+    env = dict(os.environ, PAAC_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+           "12", "--warmup", "3"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["scaling"] == "weak" and out["finite_params"]
+    assert out["config"]["global_envs"] == 64 and out["cpu_baseline"] is None
+    assert out["roofline"]["bound"] in ("mfma", "hbm") and out["value"] > 0
