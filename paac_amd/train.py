@@ -1,10 +1,13 @@
-"""Command line + creator wiring (mirrors reference train.py:14-109): identical flag names and defaults,
-`get_network_and_environment_creator(args)`, SIGINT/SIGTERM -> learner.cleanup().
+"""Command line and creator wiring of the trainer (the role of reference train.py:14-109).
 
-Extra flags (not in the reference) are namespaced `--synthetic_*`, `--sampler`, `--host_environments`.
+The flag NAMES, short forms, destinations and defaults are the reference's (train.py:79-98) -- they are the contract
+a run script depends on -- and so are `get_network_and_environment_creator(args)`, `get_arg_parser()`, `bool_arg` and
+`main(args)`.  The flags are kept as a table below; `BUILD_FLAGS` are this build's additions.
+
+  python -m paac_amd.train -g breakout --arch NATURE -df logs/
 """
 import argparse
-import copy
+import functools
 import logging
 import os
 import signal
@@ -16,17 +19,101 @@ from .policy_v_network import NaturePolicyVNetwork, NIPSPolicyVNetwork
 
 
 def bool_arg(string):
-    value = string.lower()
-    if value == 'true':
-        return True
-    elif value == 'false':
-        return False
-    else:
+    """'true' / 'false' (any case) -> bool; anything else is an argparse error."""
+    try:
+        return {"true": True, "false": False}[string.lower()]
+    except KeyError:
         raise argparse.ArgumentTypeError("Expected True or False, but got {}".format(string))
 
 
+# (option strings, dest, default, type, help)
+REFERENCE_FLAGS = (
+    (("-g",), "game", "pong", None, "game to play"),
+    (("-d", "--device"), "device", "/gpu:0", str, "'/gpu:N' selects the MI355X; '/cpu:0' is rejected (no CPU path)"),
+    (("--rom_path",), "rom_path", "./atari_roms", None, "directory with the game ROMs (ALE environments only)"),
+    (("-v", "--visualize"), "visualize", False, bool_arg, "call on_new_frame with every emulator screen"),
+    (("--e",), "e", 0.1, float, "RMSProp epsilon"),
+    (("--alpha",), "alpha", 0.99, float, "RMSProp decay of the squared-gradient average"),
+    (("-lr", "--initial_lr"), "initial_lr", 0.0224, float, "learning rate at step 0"),
+    (("-lra", "--lr_annealing_steps"), "lr_annealing_steps", 80000000, int,
+     "global steps over which the learning rate falls linearly to zero"),
+    (("--entropy",), "entropy_regularisation_strength", 0.02, float, "weight of the policy-entropy bonus"),
+    (("--clip_norm",), "clip_norm", 3.0, float, "gradient norm the update is clipped to"),
+    (("--clip_norm_type",), "clip_norm_type", "global", None, "'global' (joint norm), 'ignore' (no clipping); "
+                                                             "'local' is undefined upstream and rejected"),
+    (("--gamma",), "gamma", 0.99, float, "discount factor"),
+    (("--max_global_steps",), "max_global_steps", 80000000, int, "environment steps to train for"),
+    (("--max_local_steps",), "max_local_steps", 5, int, "t_max: steps per environment between updates"),
+    (("--arch",), "arch", "NIPS", None, "'NIPS' or 'NATURE' (anything that is not NIPS selects NATURE)"),
+    (("--single_life_episodes",), "single_life_episodes", False, bool_arg, "end an episode when a life is lost"),
+    (("-ec", "--emulator_counts"), "emulator_counts", 32, int, "environments per learner (per GPU)"),
+    (("-ew", "--emulator_workers"), "emulator_workers", 8, int, "host processes stepping host environments"),
+    (("-df", "--debugging_folder"), "debugging_folder", "logs/", str, "checkpoints, args.json, metrics.jsonl"),
+    (("-rs", "--random_start"), "random_start", True, bool_arg, "up to 30 no-op frames after every reset"),
+)
+BUILD_FLAGS = (
+    (("--sampler",), "sampler", "philox", None,
+     "device loop action sampler: 'numpy' = the reference's np.random.multinomial stream bit for bit, 'philox' = "
+     "counter-based"),
+    (("--sampler_seed",), "sampler_seed", 42, int, "seed of the counter-based sampler"),
+    (("--host_environments",), "host_environments", False, bool_arg,
+     "step BaseEnvironment plugins on the host even when a device twin exists"),
+    (("--synthetic_terminal_p",), "synthetic_terminal_p", 0.01, float, "per-step terminal probability (synthetic)"),
+    (("--synthetic_raw_frames",), "synthetic_raw_frames", False, bool_arg,
+     "synthetic environments emit two raw 210x160 screens per step (GPU max + resize + history)"),
+    (("--emulator",), "emulator", "synthetic", None,
+     "'synthetic' (paac_amd/synthetic.py) or 'ale' (Atari through an installed Arcade Learning Environment)"),
+    (("--device_preprocess",), "device_preprocess", False, bool_arg,
+     "host environments hand out raw screen pairs; max + resize + frame history run on the GPU"),
+)
+
+
+def get_arg_parser():
+    parser = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for options, dest, default, kind, text in REFERENCE_FLAGS + BUILD_FLAGS:
+        kwargs = dict(dest=dest, default=default, help=text)
+        if kind is not None:
+            kwargs["type"] = kind
+        if dest in ("sampler", "emulator"):
+            kwargs["choices"] = {"sampler": ["philox", "numpy"], "emulator": ["synthetic", "ale"]}[dest]
+        parser.add_argument(*options, **kwargs)
+    return parser
+
+
+def get_network_and_environment_creator(args, random_seed=3):
+    """-> (network_creator(name='local_learning'), environment creator); fills args.num_actions / args.random_seed
+    the way train.py:52-56 does."""
+    env_creator = environment_creator.EnvironmentCreator(args)
+    args.num_actions = env_creator.num_actions
+    args.random_seed = random_seed
+    conf = dict(num_actions=args.num_actions, device=args.device, clip_norm=args.clip_norm,
+                clip_norm_type=args.clip_norm_type,
+                entropy_regularisation_strength=args.entropy_regularisation_strength)
+    network_class = NIPSPolicyVNetwork if args.arch == 'NIPS' else NaturePolicyVNetwork
+
+    def network_creator(name='local_learning'):
+        return network_class(dict(conf, name=name))
+
+    return network_creator, env_creator
+
+
+def _stop(learner, owner_pid, signum, frame):
+    if os.getpid() != owner_pid:          # forked emulator workers inherit the handler: only the trainer reacts
+        return
+    logging.info('Signal %s detected, cleaning up.', signum)
+    learner.cleanup()
+    logging.info('Cleanup completed, shutting down...')
+    sys.exit(0)
+
+
+def setup_kill_signal_handler(learner):
+    handler = functools.partial(_stop, learner, os.getpid())
+    for signum in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(signum, handler)
+
+
 def main(args):
-    logging.debug('Configuration: {}'.format(args))
+    logging.debug('Configuration: %s', args)
     network_creator, env_creator = get_network_and_environment_creator(args)
     learner = PAACLearner(network_creator, env_creator, args)
     setup_kill_signal_handler(learner)
@@ -35,83 +122,11 @@ def main(args):
     logging.info('Finished training')
 
 
-def setup_kill_signal_handler(learner):
-    main_process_pid = os.getpid()
-
-    def signal_handler(signal, frame):
-        if os.getpid() == main_process_pid:
-            logging.info('Signal ' + str(signal) + ' detected, cleaning up.')
-            learner.cleanup()
-            logging.info('Cleanup completed, shutting down...')
-            sys.exit(0)
-
-    signal.signal(signal.SIGTERM, signal_handler)
-    signal.signal(signal.SIGINT, signal_handler)
-
-
-def get_network_and_environment_creator(args, random_seed=3):
-    env_creator = environment_creator.EnvironmentCreator(args)
-    num_actions = env_creator.num_actions
-    args.num_actions = num_actions
-    args.random_seed = random_seed
-
-    network_conf = {'num_actions': num_actions,
-                    'entropy_regularisation_strength': args.entropy_regularisation_strength,
-                    'device': args.device,
-                    'clip_norm': args.clip_norm,
-                    'clip_norm_type': args.clip_norm_type}
-    if args.arch == 'NIPS':
-        network = NIPSPolicyVNetwork
-    else:
-        network = NaturePolicyVNetwork
-
-    def network_creator(name='local_learning'):
-        copied_network_conf = copy.copy(network_conf)
-        copied_network_conf['name'] = name
-        return network(copied_network_conf)
-
-    return network_creator, env_creator
-
-
-def get_arg_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-g', default='pong', help='Name of game', dest='game')
-    parser.add_argument('-d', '--device', default='/gpu:0', type=str, help="Device to be used ('/gpu:0', '/gpu:1',...); '/cpu:0' is rejected: this build is MI355X-only", dest="device")
-    parser.add_argument('--rom_path', default='./atari_roms', help='Directory where the game roms are located (needed for ALE environment)', dest="rom_path")
-    parser.add_argument('-v', '--visualize', default=False, type=bool_arg, help="0: no visualization of emulator; 1: all emulators, for all actors, are visualized; 2: only 1 emulator (for one of the actors) is visualized", dest="visualize")
-    parser.add_argument('--e', default=0.1, type=float, help="Epsilon for the Rmsprop and Adam optimizers", dest="e")
-    parser.add_argument('--alpha', default=0.99, type=float, help="Discount factor for the history/coming gradient, for the Rmsprop optimizer", dest="alpha")
-    parser.add_argument('-lr', '--initial_lr', default=0.0224, type=float, help="Initial value for the learning rate. Default = 0.0224", dest="initial_lr")
-    parser.add_argument('-lra', '--lr_annealing_steps', default=80000000, type=int, help="Nr. of global steps during which the learning rate will be linearly annealed towards zero", dest="lr_annealing_steps")
-    parser.add_argument('--entropy', default=0.02, type=float, help="Strength of the entropy regularization term (needed for actor-critic)", dest="entropy_regularisation_strength")
-    parser.add_argument('--clip_norm', default=3.0, type=float, help="If clip_norm_type is local/global, grads will be clipped at the specified maximum (avaerage) L2-norm", dest="clip_norm")
-    parser.add_argument('--clip_norm_type', default="global", help="Whether to clip grads by their norm or not. Values: ignore (no clipping), local (layer-wise norm), global (global norm)", dest="clip_norm_type")
-    parser.add_argument('--gamma', default=0.99, type=float, help="Discount factor", dest="gamma")
-    parser.add_argument('--max_global_steps', default=80000000, type=int, help="Max. number of training steps", dest="max_global_steps")
-    parser.add_argument('--max_local_steps', default=5, type=int, help="Number of steps to gain experience from before every update.", dest="max_local_steps")
-    parser.add_argument('--arch', default='NIPS', help="Which network architecture to use: from the NIPS or NATURE paper", dest="arch")
-    parser.add_argument('--single_life_episodes', default=False, type=bool_arg, help="If True, training episodes will be terminated when a life is lost (for games)", dest="single_life_episodes")
-    parser.add_argument('-ec', '--emulator_counts', default=32, type=int, help="The amount of emulators per agent. Default is 32.", dest="emulator_counts")
-    parser.add_argument('-ew', '--emulator_workers', default=8, type=int, help="The amount of emulator workers per agent. Default is 8.", dest="emulator_workers")
-    parser.add_argument('-df', '--debugging_folder', default='logs/', type=str, help="Folder where to save the debugging information.", dest="debugging_folder")
-    parser.add_argument('-rs', '--random_start', default=True, type=bool_arg, help="Whether or not to start with 30 noops for each env. Default True", dest="random_start")
-    # -- additions of this build --
-    parser.add_argument('--sampler', default='philox', choices=['philox', 'numpy'], help="Action sampler of the device-resident loop: 'numpy' = the reference's np.random.multinomial stream bit for bit, 'philox' = counter-based", dest="sampler")
-    parser.add_argument('--sampler_seed', default=42, type=int, dest="sampler_seed")
-    parser.add_argument('--host_environments', default=False, type=bool_arg, help="Step BaseEnvironment plugins on the host even when a device twin exists", dest="host_environments")
-    parser.add_argument('--synthetic_terminal_p', default=0.01, type=float, dest="synthetic_terminal_p")
-    parser.add_argument('--synthetic_raw_frames', default=False, type=bool_arg, help="Synthetic envs emit two raw 210x160 frames per step (max + nearest resize + stack on the GPU)", dest="synthetic_raw_frames")
-    parser.add_argument('--emulator', default='synthetic', choices=['synthetic', 'ale'], help="Environments: the synthetic family of paac_amd/synthetic.py, or Atari through an installed Arcade Learning Environment (paac_amd/atari_emulator.py)", dest="emulator")
-    parser.add_argument('--device_preprocess', default=False, type=bool_arg, help="Host environments hand out raw 210x160 screen pairs; max + resize + frame history run on the GPU", dest="device_preprocess")
-    return parser
-
-
 save_args = logger_utils.save_args      # logger_utils.py:15-20
 
 
 if __name__ == '__main__':
     logging.basicConfig(stream=sys.stdout, level=logging.DEBUG)
-    args = get_arg_parser().parse_args()
-    save_args(args, args.debugging_folder)
-    logging.debug(args)
-    main(args)
+    cli_args = get_arg_parser().parse_args()
+    save_args(cli_args, cli_args.debugging_folder)
+    main(cli_args)
