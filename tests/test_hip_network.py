@@ -38,7 +38,10 @@ def unflatten(ctx, flat):
 
 
 @pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 32), ("NATURE", 4, 160), ("NATURE", 18, 7), ("NATURE", 6, 1),
-                                      ("NIPS", 6, 40), ("NIPS", 4, 33), ("NIPS", 18, 160)])
+                                      ("NIPS", 6, 40), ("NIPS", 4, 33), ("NIPS", 18, 160),
+                                      ("NATURE", 4, 192),      # the device loop's training forward: N*(T+1) rows
+                                      ("NATURE", 4, 1536),     # 256 envs x (5+1): size heuristics instead of the tuned table
+                                      ("NIPS", 6, 1280)])
 def test_forward_parity(arch, A, B):
     from paac_amd import hip_ops
     params, states, idx, y, adv = make_case(arch, A, B, seed=1)
@@ -68,7 +71,9 @@ def test_forward_parity(arch, A, B):
 
 
 @pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NATURE", 6, 40), ("NATURE", 18, 9), ("NIPS", 6, 40),
-                                      ("NIPS", 4, 160), ("NATURE", 4, 320)])
+                                      ("NIPS", 4, 160), ("NATURE", 4, 320),
+                                      ("NATURE", 4, 1280),     # 256 envs x t_max 5 (BASELINE configs[2]): heuristics
+                                      ("NIPS", 6, 640)])
 def test_backward_parity(arch, A, B):
     from paac_amd import hip_ops
     params, states, idx, y, adv = make_case(arch, A, B, seed=2)
