@@ -99,6 +99,7 @@ __device__ __forceinline__ f32x4 load4(const void* base, long off) {
 // sentinel offset and the hardware range check returns zeros.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned kOob = 0x80000000u;   // >= num_records of any tensor here (< 2 GiB)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -159,11 +160,20 @@ __device__ __forceinline__ void storev(float* p, const f32x4 v) {
 // AP/BP: fragment pattern of A / B.  TM/TN: 16x16 tiles per wave (for a FRAG_MN side this is also the vector
 // width V in {1,2,4}).  NWM x NWN x WK waves per workgroup.  BCO: channels per tap of a FRAG_K B operand.
 // The contraction is a device-side body: one workgroup = one call of run(p, workgroup id, LDS).
+// XB ("exact bf16"): for the u8-frame operand of conv1.  A byte is exact in bf16 and an fp32 weight / gradient splits
+// EXACTLY into three bf16 terms (8 + 8 + 8 mantissa bits), so x * w = x*w_hi + x*w_mid + x*w_lo with every product
+// exact and the sums in fp32 -- the arithmetic of the fp32 MFMA -- on v_mfma_f32_16x16x32_bf16, which retires a 32-deep
+// K step in 16 cycles where the fp32 form needs 8 x 32.  The 1/255 input scale moves to the epilogue.  A K stage is
+// then two 16-wide groups (the lane's 4 + 4 k values make the 8 the instruction wants; the K permutation is the
+// same for A and B, so it is free).
 template <class G_, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI_, bool BIASROW,
-          int PF>
+          int PF, bool XB = false>
 struct Dmm {
   using G = G_;
   static constexpr int EPI = EPI_;
+  static constexpr int GS = XB ? 2 : 1;          // 16-wide K groups per pipeline stage
+  static constexpr int KSTAGE = 16 * GS;
+  static_assert(!XB || (U8 && BP == FRAG_MN), "exact-bf16 path: u8 A operand, fp32 FRAG_MN B operand");
   static constexpr int THREADS = 64 * NWM * NWN * WK;
   static constexpr int M_TILE = NWM * TM * 16, N_TILE = NWN * TN * 16, WAVES_K = WK;
   static constexpr int NA = (AP == FRAG_K) ? TM : 4;
@@ -278,29 +288,35 @@ struct Dmm {
   }
 
   // ---- K range of this wave -------------------------------------------------------------------------
-  const int ngroups = (p.K + 15) / 16;
+  const int ngroups = (p.K + KSTAGE - 1) / KSTAGE;   // pipeline stages of KSTAGE k values
   const int part = ((EPI == EPI_SLAB) ? z : 0) * WK + wk;
   const int g_begin = min(part * p.groups_per_part, ngroups);
   const int g_end = min(g_begin + p.groups_per_part, ngroups);
   const int ng = g_end - g_begin;
-  const int k_end = min(p.K, g_end * 16);   // FRAG_MN A rows at or past this read as zero
+  const int k_end = min(p.K, g_end * KSTAGE);   // FRAG_MN A rows at or past this read as zero
   const int tap_base = (BP == FRAG_K) ? p.tap_base[par] : 0;
 
   // ---- fragment loads for K group `g` (k16 = 16 g) --------------------------------------------------
   // Every call issues the same NA + NB buffer loads whatever `live` is -- a group past the end of this wave's
   // range is loaded with all lanes out of range (no memory access, zeros, never consumed) -- so the K loop has
   // no branch around its loads and the compiler's s_waitcnt placement keeps the full prefetch distance.
-  f32x4 fa[RING][NA], fb[RING][NB];
+  f32x4 fa[RING][GS][NA], fb[RING][GS][NB];
+  unsigned ua[RING][GS][NA];                    // XB: the raw bytes of the A operand (4 per lane and load)
   auto load_group = [&](int slot, int g, bool live) {
-    const int k16 = g * 16;                     // wave-uniform
     const unsigned kill = live ? 0u : kOob;     // wave-uniform
+#pragma unroll
+    for (int gs = 0; gs < GS; ++gs) {
+    const int k16 = (g * GS + gs) * 16;         // wave-uniform
     if constexpr (AP == FRAG_K) {
       const int kh = k16 / G::KWC;
       const int kwc = k16 - kh * G::KWC;
       const unsigned goff = live ? (unsigned)(kh * (G::IW * G::C) + kwc) * ES : 0u;
       if constexpr (!G::PADDED) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) fa[slot][t] = bload4<U8>(rsA, a_voff[t] | kill, goff);
+        for (int t = 0; t < TM; ++t) {
+          if constexpr (XB) ua[slot][gs][t] = __builtin_amdgcn_raw_buffer_load_b32(rsA, a_voff[t] | kill, goff, 0);
+          else fa[slot][gs][t] = bload4<U8>(rsA, a_voff[t] | kill, goff);
+        }
       } else {
         const int kw = kwc / G::C;
 #pragma unroll
@@ -308,7 +324,7 @@ struct Dmm {
           const int iy = a_iy0[t] + kh;
           const int ix = a_ix0[t] + kw;
           const bool ok = live && (iy >= 0) && (iy < G::IH) && (ix >= 0) && (ix < G::IW);
-          fa[slot][t] = bload4<U8>(rsA, ok ? a_voff[t] + goff : kOob, 0);
+          fa[slot][gs][t] = bload4<U8>(rsA, ok ? a_voff[t] + goff : kOob, 0);
         }
       }
     } else {
@@ -329,9 +345,10 @@ struct Dmm {
         }
         if constexpr (U8) {
           static_assert(!U8 || TM == 4, "u8 FRAG_MN loads are uchar4");
-          fa[slot][s] = bload4<true>(rsA, off, 0);
+          if constexpr (XB) ua[slot][gs][s] = __builtin_amdgcn_raw_buffer_load_b32(rsA, off, 0, 0);
+          else fa[slot][gs][s] = bload4<true>(rsA, off, 0);
         } else {
-          fa[slot][s] = bloadv<TM>(rsA, off, 0);
+          fa[slot][gs][s] = bloadv<TM>(rsA, off, 0);
         }
       }
     }
@@ -342,14 +359,15 @@ struct Dmm {
       const int tw = tap - th * G::KW;
       const unsigned goff = live ? (unsigned)(tap_base + th * p.tap_sh + tw * p.tap_sw + co) * 4u : 0u;
 #pragma unroll
-      for (int t = 0; t < TN; ++t) fb[slot][t] = bload4<false>(rsB, b_voff[t] | kill, goff);
+      for (int t = 0; t < TN; ++t) fb[slot][gs][t] = bload4<false>(rsB, b_voff[t] | kill, goff);
     } else {
       // the whole offset goes through the range-checked VGPR offset: rows >= K (the tail of a K that is not a
       // multiple of 16) and dead groups read as zero
       const unsigned goff = live ? (unsigned)(k16 * p.ldb) * 4u : kOob;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) fb[slot][s] = bloadv<TN>(rsB, b_voff[s] + goff, 0);
+      for (int s = 0; s < 4; ++s) fb[slot][gs][s] = bloadv<TN>(rsB, b_voff[s] + goff, 0);
     }
+    }   // gs
   };
 
   f32x4 acc[TM][TN];
@@ -375,18 +393,79 @@ struct Dmm {
       const int gi = gb + st;
       if (gi >= ng) goto k_done;   // side exit: nothing joins the loop body, the wait counts stay exact
       load_group((st + PF) % RING, g_begin + gi + PF, gi + PF < ng);
+      if constexpr (!XB) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = (AP == FRAG_K) ? fa[st][0][i][s] : fa[st][0][s][i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float bv = (BP == FRAG_K) ? fb[st][0][j][s] : fb[st][0][s][j];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+          }
+          if constexpr (BIASROW) bsum += fb[st][0][s];
+        }
+      } else {
+        // lane (i, kq) holds k = 4kq + s of both groups of the stage: element e = 4 gs + s of the 8 the MFMA takes
+        bf16x8 a8[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const float av = (AP == FRAG_K) ? fa[st][i][s] : fa[st][s][i];
+          u32x4 w;
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float bv = (BP == FRAG_K) ? fb[st][j][s] : fb[st][s][j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+          for (int gs = 0; gs < 2; ++gs) {
+            unsigned b[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              // FRAG_K: the dword of tile i carries k = 4kq .. 4kq+3; FRAG_MN: dword s carries the 4 tiles of k = 4kq+s
+              const unsigned byte = (AP == FRAG_K) ? (ua[st][gs][i] >> (8 * s)) & 255u : (ua[st][gs][s] >> (8 * i)) & 255u;
+              b[s] = __builtin_bit_cast(unsigned, (float)byte) >> 16;    // an integer < 256 is exact in bf16
+            }
+            w[2 * gs] = b[0] | (b[1] << 16);
+            w[2 * gs + 1] = b[2] | (b[3] << 16);
+          }
+          a8[i] = __builtin_bit_cast(bf16x8, w);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          u32x4 hi, mid, lo;
+#pragma unroll
+          for (int gs = 0; gs < 2; ++gs) {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const float x = fb[st][gs][s][j];
+              const unsigned xh = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;      // top 8 mantissa bits (truncated)
+              const float r1 = x - __builtin_bit_cast(float, xh);                     // exact
+              const unsigned xm = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;     // next 8
+              const float r2 = r1 - __builtin_bit_cast(float, xm);                    // exact, <= 8 bits left
+              h[s] = xh >> 16;
+              m[s] = xm >> 16;
+              l[s] = __builtin_bit_cast(unsigned, r2) >> 16;
+            }
+            hi[2 * gs] = h[0] | (h[1] << 16);
+            hi[2 * gs + 1] = h[2] | (h[3] << 16);
+            mid[2 * gs] = m[0] | (m[1] << 16);
+            mid[2 * gs + 1] = m[2] | (m[3] << 16);
+            lo[2 * gs] = l[0] | (l[1] << 16);
+            lo[2 * gs + 1] = l[2] | (l[3] << 16);
+          }
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bm = __builtin_bit_cast(bf16x8, mid),
+                       bl = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[i], bl, acc[i][j], 0, 0, 0);   // small terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[i], bh, acc[i][j], 0, 0, 0);
           }
         }
-        if constexpr (BIASROW) bsum += fb[st][s];
+        if constexpr (BIASROW) {
+#pragma unroll
+          for (int gs = 0; gs < 2; ++gs)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bsum += fb[st][gs][s];
+        }
       }
     }
   }
@@ -452,6 +531,7 @@ k_done:
       } else {
         c[tn] = acc[tm][tn];
       }
+      if constexpr (XB) c[tn] *= kInputScale;   // the products were taken on the raw bytes (networks.py:115)
     }
     if constexpr (BP == FRAG_MN) {
 #pragma unroll
@@ -543,7 +623,7 @@ __global__ __launch_bounds__(D::THREADS) void dmm_kernel(const GemmArgs p) {
 // Fills the launch geometry of `a` for body D; returns the number of workgroups.
 template <class D>
 inline long prepare_dmm(GemmArgs& a, int zdim, int ksplit_z, int xcd_dim) {
-  const int ngroups = (a.K + 15) / 16;
+  const int ngroups = (a.K + D::KSTAGE - 1) / D::KSTAGE;
   const int parts = D::WAVES_K * ((D::EPI == EPI_SLAB) ? ksplit_z : 1);
   a.groups_per_part = (ngroups + parts - 1) / parts;
   a.MT = (a.M + D::M_TILE - 1) / D::M_TILE;

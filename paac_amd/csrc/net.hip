@@ -93,6 +93,7 @@ static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int targe
 #define PAAC_WGRAD_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(2, 4, 8, 2) X(3, 4, 4, 3) X(4, 2, 4, 3) X(5, 2, 8, 3) X(6, 4, 1, 3) \
                            X(7, 4, 1, 4) X(8, 4, 2, 3)
 constexpr int kFwdCfgs = 13, kDgradCfgs = 12, kWgradCfgs = 9;
+constexpr int kExactBf16 = 100;   // cfg ids from here on: the same table entry on the exact-bf16 path (u8 operand only)
 
 // Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
 template <class G, bool U8, int NDIM, int EPI>
@@ -110,7 +111,20 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
   if (cfg < 0) {
     const long w = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN)) * ksplit;
     cfg = (w <= 256) ? 0 : (w <= 1024) ? 3 : (w <= 4096) ? 4 : 5;
+    if (U8) cfg += kExactBf16;   // the u8 operand always takes the exact-bf16 path (faster at every size measured)
     xcd = -1;
+  }
+  if constexpr (U8) {
+    if (cfg >= kExactBf16) {   // conv1 on the bf16 MFMA with exactly split weights (dmm.h: XB), same tile table
+      switch (cfg - kExactBf16) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF, true>>(g, ksplit, ksplit, xcd, s); break;
+        PAAC_FWD_CFGS(X)
+#undef X
+        default: break;
+      }
+      return ksplit;
+    }
   }
   switch (cfg) {
 #define X(id, TM, NWM, WK, PF) \
@@ -160,8 +174,8 @@ template <int NDIM>
 struct WgradN {
   static constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
 };
-template <class G, bool U8, int NDIM, int TM, int WK, int PF>
-using WgradBody = Dmm<G, U8, FRAG_MN, FRAG_MN, TM, WgradN<NDIM>::VN, 1, 1, WK, 1, EPI_SLAB, true, PF>;
+template <class G, bool U8, int NDIM, int TM, int WK, int PF, bool XB = false>
+using WgradBody = Dmm<G, U8, FRAG_MN, FRAG_MN, TM, WgradN<NDIM>::VN, 1, 1, WK, 1, EPI_SLAB, true, PF, XB>;
 
 template <bool U8, int NDIM>
 static void resolve_wgrad(const GemmArgs& g, int max_split, Tune t, int& cfg, int& ks, int& xcd) {
@@ -181,16 +195,33 @@ static void resolve_wgrad(const GemmArgs& g, int max_split, Tune t, int& cfg, in
       ks = 1;
       xcd = -1;
     }
+    if (U8) cfg += kExactBf16;
   }
   if (ks < 1) ks = 1;
   if (ks > max_split) ks = max_split;
-  if (U8 && (cfg == 4 || cfg == 5)) cfg = 0;   // u8 patches are loaded as uchar4: 64 features per wave only
+  const int plain = cfg >= kExactBf16 ? cfg - kExactBf16 : cfg;
+  if (U8 && (plain == 4 || plain == 5)) cfg -= plain;   // u8 patches are loaded as uchar4: 64 features per wave only
+  if (!U8 && cfg >= kExactBf16) cfg = plain;
 }
 
 template <class G, bool U8, int NDIM>
 static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s) {
   int cfg, ks, xcd;
   resolve_wgrad<U8, NDIM>(g, max_split, t, cfg, ks, xcd);
+  if constexpr (U8) {
+    if (cfg >= kExactBf16) {
+      switch (cfg - kExactBf16) {
+#define X(id, TM, WK, PF)                                                                         \
+  case id:                                                                                        \
+    if constexpr (TM == 4) launch_dmm<WgradBody<G, U8, NDIM, TM, WK, PF, true>>(g, ks, ks, xcd, s); \
+    break;
+        PAAC_WGRAD_CFGS(X)
+#undef X
+        default: break;
+      }
+      return ks;
+    }
+  }
   switch (cfg) {
 #define X(id, TM, WK, PF)                                                                   \
   case id:                                                                                  \
@@ -475,8 +506,8 @@ void default_tuning(paac_ctx* c) {
   if (c->cfg.arch != PAAC_ARCH_NATURE || c->max_batch > 512) return;
   // tools/tune_gemm.py on MI355X, 32 envs x t_max 5: acting batch 32 (class 0); training forward over 192 rows and
   // backward over 160 (class 1)
-  c->tune[OP_CONV1_FWD][0] = Tune{7, 0, -1};
-  c->tune[OP_CONV1_FWD][1] = Tune{4, 0, -1};
+  c->tune[OP_CONV1_FWD][0] = Tune{kExactBf16 + 4, 0, -1};
+  c->tune[OP_CONV1_FWD][1] = Tune{kExactBf16 + 10, 0, -1};
   c->tune[OP_CONV2_FWD][1] = Tune{7, 0, -1};
   c->tune[OP_CONV3_FWD][0] = Tune{1, 0, -1};
   c->tune[OP_CONV3_FWD][1] = Tune{7, 0, -1};
@@ -488,6 +519,6 @@ void default_tuning(paac_ctx* c) {
   c->tune[OP_CONV3_DGRAD][1] = Tune{2, 0, -1};
   c->tune[OP_CONV2_WGRAD][1] = Tune{3, 32, 2};
   c->tune[OP_CONV2_DGRAD][1] = Tune{3, 0, 0};
-  c->tune[OP_CONV1_WGRAD][1] = Tune{2, 64, 2};
+  c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 2, 64, 2};
 }
 }  // namespace paac

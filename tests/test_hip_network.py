@@ -218,3 +218,43 @@ def test_errors_are_loud():
     with pytest.raises(_lib.PaacHipError):
         hip_ops.Context(1, 99, max_batch=8)
     ctx.close()
+
+
+@pytest.mark.parametrize("B,fwd_cfg,wgrad_cfg", [(32, 107, None), (160, 104, 102), (192, 100, 100), (37, 112, 108)])
+def test_conv1_exact_bf16_path(B, fwd_cfg, wgrad_cfg):
+    """conv1 on v_mfma_f32_16x16x32_bf16 with the u8 pixels as exact bf16 and the fp32 weights / output gradients split
+    exactly into three bf16 terms (dmm.h: XB): same parity bars as the fp32-MFMA path, and the two paths agree to
+    fp32 rounding."""
+    from paac_amd import hip_ops, _lib
+    arch, A = "NATURE", 4
+    params, states, idx, y, adv = make_case(arch, A, B, seed=8)
+    ref = onet.forward(params, states, arch, dtype=np.float64, keep=True)
+    outs = {}
+    for label, fc, wc in (("fp32", None, None), ("bf16x3", fwd_cfg, wgrad_cfg)):
+        ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+        if fc is not None:
+            for cls in (0, 1):
+                _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, 0, cls, fc, 0, -1), "set_tuning")
+            if wc is not None:
+                _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, 10, 1 if B > 64 else 0, wc, 32, 2), "set_tuning")
+        p = upload_params(ctx, params)
+        s = torch.from_numpy(states).cuda()
+        logits = torch.zeros((B, A), device="cuda")
+        values = torch.zeros((B,), device="cuda")
+        ctx.forward(p, s, logits, None, values)
+        a1 = ctx.debug_activation(1, B).cpu().numpy()
+        assert np.abs(a1 - ref["cache"]["a1"].reshape(-1)).max() < 2e-5
+        assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+        assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
+        grad = torch.zeros(ctx.layout["total"], device="cuda")
+        ctx.loss_backward(p, s, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(adv).cuda(),
+                          0.02, grad)
+        torch.cuda.synchronize()
+        outs[label] = (a1, unflatten(ctx, grad))
+        ctx.close()
+    a_ref, g_ref = outs["fp32"]
+    a_new, g_new = outs["bf16x3"]
+    assert np.abs(a_new - a_ref).max() < 2e-6
+    for name in ("conv1_weights", "conv1_biases"):
+        scale = max(np.abs(g_ref[name]).max(), 1e-6)
+        assert np.abs(g_new[name] - g_ref[name]).max() / scale < 2e-5, name
