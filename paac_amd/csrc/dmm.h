@@ -160,20 +160,26 @@ __device__ __forceinline__ void storev(float* p, const f32x4 v) {
 // AP/BP: fragment pattern of A / B.  TM/TN: 16x16 tiles per wave (for a FRAG_MN side this is also the vector
 // width V in {1,2,4}).  NWM x NWN x WK waves per workgroup.  BCO: channels per tap of a FRAG_K B operand.
 // The contraction is a device-side body: one workgroup = one call of run(p, workgroup id, LDS).
-// XB ("exact bf16"): for the u8-frame operand of conv1.  A byte is exact in bf16 and an fp32 weight / gradient splits
+// XB = 1 ("exact bf16"): for the u8-frame operand of conv1.  A byte is exact in bf16 and an fp32 weight / gradient splits
 // EXACTLY into three bf16 terms (8 + 8 + 8 mantissa bits), so x * w = x*w_hi + x*w_mid + x*w_lo with every product
 // exact and the sums in fp32 -- the arithmetic of the fp32 MFMA -- on v_mfma_f32_16x16x32_bf16, which retires a 32-deep
 // K step in 16 cycles where the fp32 form needs 8 x 32.  The 1/255 input scale moves to the epilogue.  A K stage is
 // then two 16-wide groups (the lane's 4 + 4 k values make the 8 the instruction wants; the K permutation is the
 // same for A and B, so it is free).
+// XB = 2: both operands fp32, each split into (hi, mid, lo) bf16 terms; the six products down to 2^-16 of the leading
+// one are accumulated (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi), the three dropped ones are below 2^-23 of it --
+// the size of one fp32 rounding, of which the fp32 MFMA commits one per accumulated product anyway.  Six 16-cycle
+// MFMAs replace eight 32-cycle ones per 32-deep K step; the splitting costs VALU work, so it pays for the
+// MFMA-bound shapes only (the tuner decides per op).
 template <class G_, bool U8, int AP, int BP, int TM, int TN, int NWM, int NWN, int WK, int BCO, int EPI_, bool BIASROW,
-          int PF, bool XB = false>
+          int PF, int XB = 0>
 struct Dmm {
   using G = G_;
   static constexpr int EPI = EPI_;
   static constexpr int GS = XB ? 2 : 1;          // 16-wide K groups per pipeline stage
   static constexpr int KSTAGE = 16 * GS;
-  static_assert(!XB || (U8 && BP == FRAG_MN), "exact-bf16 path: u8 A operand, fp32 FRAG_MN B operand");
+  static_assert(XB != 1 || (U8 && BP == FRAG_MN), "exact-bf16 path: u8 A operand, fp32 FRAG_MN B operand");
+  static_assert(XB != 2 || !U8, "split path: fp32 operands");
   static constexpr int THREADS = 64 * NWM * NWN * WK;
   static constexpr int M_TILE = NWM * TM * 16, N_TILE = NWN * TN * 16, WAVES_K = WK;
   static constexpr int NA = (AP == FRAG_K) ? TM : 4;
@@ -314,7 +320,7 @@ struct Dmm {
       if constexpr (!G::PADDED) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-          if constexpr (XB) ua[slot][gs][t] = __builtin_amdgcn_raw_buffer_load_b32(rsA, a_voff[t] | kill, goff, 0);
+          if constexpr (XB == 1) ua[slot][gs][t] = __builtin_amdgcn_raw_buffer_load_b32(rsA, a_voff[t] | kill, goff, 0);
           else fa[slot][gs][t] = bload4<U8>(rsA, a_voff[t] | kill, goff);
         }
       } else {
@@ -345,7 +351,7 @@ struct Dmm {
         }
         if constexpr (U8) {
           static_assert(!U8 || TM == 4, "u8 FRAG_MN loads are uchar4");
-          if constexpr (XB) ua[slot][gs][s] = __builtin_amdgcn_raw_buffer_load_b32(rsA, off, 0, 0);
+          if constexpr (XB == 1) ua[slot][gs][s] = __builtin_amdgcn_raw_buffer_load_b32(rsA, off, 0, 0);
           else fa[slot][gs][s] = bload4<true>(rsA, off, 0);
         } else {
           fa[slot][gs][s] = bloadv<TM>(rsA, off, 0);
@@ -393,7 +399,7 @@ struct Dmm {
       const int gi = gb + st;
       if (gi >= ng) goto k_done;   // side exit: nothing joins the loop body, the wait counts stay exact
       load_group((st + PF) % RING, g_begin + gi + PF, gi + PF < ng);
-      if constexpr (!XB) {
+      if constexpr (XB == 0) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -406,6 +412,66 @@ struct Dmm {
             }
           }
           if constexpr (BIASROW) bsum += fb[st][0][s];
+        }
+      } else if constexpr (XB == 2) {
+        // three bf16 planes per operand tile; element e = 4 gs + s of a lane's 8 is k = 4kq + s of group gs
+        auto split3 = [&](const float (&x)[8], bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+          u32x4 hi, mid, lo;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            unsigned h[2], m[2], l[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const unsigned xh = __builtin_bit_cast(unsigned, x[e + u]) & 0xFFFF0000u;
+              const float r1 = x[e + u] - __builtin_bit_cast(float, xh);
+              const unsigned xm = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+              const float r2 = r1 - __builtin_bit_cast(float, xm);
+              h[u] = xh >> 16;
+              m[u] = xm >> 16;
+              l[u] = __builtin_bit_cast(unsigned, r2) >> 16;
+            }
+            hi[e / 2] = h[0] | (h[1] << 16);
+            mid[e / 2] = m[0] | (m[1] << 16);
+            lo[e / 2] = l[0] | (l[1] << 16);
+          }
+          ph = __builtin_bit_cast(bf16x8, hi);
+          pm = __builtin_bit_cast(bf16x8, mid);
+          pl = __builtin_bit_cast(bf16x8, lo);
+        };
+        bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float x[8];
+#pragma unroll
+          for (int gs = 0; gs < 2; ++gs)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x[4 * gs + s] = (AP == FRAG_K) ? fa[st][gs][i][s] : fa[st][gs][s][i];
+          split3(x, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float x[8];
+#pragma unroll
+          for (int gs = 0; gs < 2; ++gs)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x[4 * gs + s] = (BP == FRAG_K) ? fb[st][gs][j][s] : fb[st][gs][s][j];
+          bf16x8 bh, bm, bl;
+          split3(x, bh, bm, bl);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {   // smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          }
+        }
+        if constexpr (BIASROW) {
+#pragma unroll
+          for (int gs = 0; gs < 2; ++gs)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bsum += fb[st][gs][s];
         }
       } else {
         // lane (i, kq) holds k = 4kq + s of both groups of the stage: element e = 4 gs + s of the 8 the MFMA takes
@@ -531,7 +597,7 @@ k_done:
       } else {
         c[tn] = acc[tm][tn];
       }
-      if constexpr (XB) c[tn] *= kInputScale;   // the products were taken on the raw bytes (networks.py:115)
+      if constexpr (XB == 1) c[tn] *= kInputScale;   // the products were taken on the raw bytes (networks.py:115)
     }
     if constexpr (BP == FRAG_MN) {
 #pragma unroll

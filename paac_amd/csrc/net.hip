@@ -94,6 +94,8 @@ static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int targe
                            X(7, 4, 1, 4) X(8, 4, 2, 3)
 constexpr int kFwdCfgs = 13, kDgradCfgs = 12, kWgradCfgs = 9;
 constexpr int kExactBf16 = 100;   // cfg ids from here on: the same table entry on the exact-bf16 path (u8 operand only)
+constexpr int kSplitBf16 = 200;   // ... on the six-product split-bf16 path (fp32 operands; dmm.h: XB = 2)
+constexpr int split_pf(int pf) { return pf > 2 ? 2 : pf; }   // a stage is two K groups there: shallower ring
 
 // Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
 template <class G, bool U8, int NDIM, int EPI>
@@ -118,7 +120,19 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
     if (cfg >= kExactBf16) {   // conv1 on the bf16 MFMA with exactly split weights (dmm.h: XB), same tile table
       switch (cfg - kExactBf16) {
 #define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF, true>>(g, ksplit, ksplit, xcd, s); break;
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF, 1>>(g, ksplit, ksplit, xcd, s); break;
+        PAAC_FWD_CFGS(X)
+#undef X
+        default: break;
+      }
+      return ksplit;
+    }
+  }
+  if constexpr (!U8) {
+    if (cfg >= kSplitBf16) {
+      switch (cfg - kSplitBf16) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, split_pf(PF), 2>>(g, ksplit, ksplit, xcd, s); break;
         PAAC_FWD_CFGS(X)
 #undef X
         default: break;
@@ -141,8 +155,8 @@ template <int NDIM>
 struct DgradN {
   static constexpr int TN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
 };
-template <class G, int NDIM, int BCO, int EPI, int TM, int NWM, int WK, int PF>
-using DgradBody = Dmm<G, false, FRAG_K, FRAG_K, TM, DgradN<NDIM>::TN, NWM, 1, WK, BCO, EPI, false, PF>;
+template <class G, int NDIM, int BCO, int EPI, int TM, int NWM, int WK, int PF, int XB = 0>
+using DgradBody = Dmm<G, false, FRAG_K, FRAG_K, TM, DgradN<NDIM>::TN, NWM, 1, WK, BCO, EPI, false, PF, XB>;
 
 template <int NDIM, int EPI>
 static void resolve_dgrad(const GemmArgs& g, int zdim, Tune t, int& cfg, int& xcd) {
@@ -160,6 +174,16 @@ template <class G, int NDIM, int BCO, int EPI>
 static void launch_dgrad(const GemmArgs& g, int zdim, Tune t, hipStream_t s) {
   int cfg, xcd;
   resolve_dgrad<NDIM, EPI>(g, zdim, t, cfg, xcd);
+  if (cfg >= kSplitBf16) {
+    switch (cfg - kSplitBf16) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<DgradBody<G, NDIM, BCO, EPI, TM, NWM, WK, split_pf(PF), 2>>(g, zdim, 1, xcd, s); break;
+      PAAC_DGRAD_CFGS(X)
+#undef X
+      default: break;
+    }
+    return;
+  }
   switch (cfg) {
 #define X(id, TM, NWM, WK, PF) \
   case id: launch_dmm<DgradBody<G, NDIM, BCO, EPI, TM, NWM, WK, PF>>(g, zdim, 1, xcd, s); break;
@@ -174,7 +198,7 @@ template <int NDIM>
 struct WgradN {
   static constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
 };
-template <class G, bool U8, int NDIM, int TM, int WK, int PF, bool XB = false>
+template <class G, bool U8, int NDIM, int TM, int WK, int PF, int XB = 0>
 using WgradBody = Dmm<G, U8, FRAG_MN, FRAG_MN, TM, WgradN<NDIM>::VN, 1, 1, WK, 1, EPI_SLAB, true, PF, XB>;
 
 template <bool U8, int NDIM>
@@ -199,9 +223,10 @@ static void resolve_wgrad(const GemmArgs& g, int max_split, Tune t, int& cfg, in
   }
   if (ks < 1) ks = 1;
   if (ks > max_split) ks = max_split;
-  const int plain = cfg >= kExactBf16 ? cfg - kExactBf16 : cfg;
+  const int plain = cfg % kExactBf16;
   if (U8 && (plain == 4 || plain == 5)) cfg -= plain;   // u8 patches are loaded as uchar4: 64 features per wave only
-  if (!U8 && cfg >= kExactBf16) cfg = plain;
+  if (U8 && cfg >= kSplitBf16) cfg = kExactBf16 + plain;              // u8 operand: exact path, not the split one
+  if (!U8 && cfg >= kExactBf16 && cfg < kSplitBf16) cfg = plain;
 }
 
 template <class G, bool U8, int NDIM>
@@ -213,8 +238,20 @@ static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s)
       switch (cfg - kExactBf16) {
 #define X(id, TM, WK, PF)                                                                         \
   case id:                                                                                        \
-    if constexpr (TM == 4) launch_dmm<WgradBody<G, U8, NDIM, TM, WK, PF, true>>(g, ks, ks, xcd, s); \
+    if constexpr (TM == 4) launch_dmm<WgradBody<G, U8, NDIM, TM, WK, PF, 1>>(g, ks, ks, xcd, s); \
     break;
+        PAAC_WGRAD_CFGS(X)
+#undef X
+        default: break;
+      }
+      return ks;
+    }
+  }
+  if constexpr (!U8) {
+    if (cfg >= kSplitBf16) {
+      switch (cfg - kSplitBf16) {
+#define X(id, TM, WK, PF) \
+  case id: launch_dmm<WgradBody<G, U8, NDIM, TM, WK, split_pf(PF), 2>>(g, ks, ks, xcd, s); break;
         PAAC_WGRAD_CFGS(X)
 #undef X
         default: break;
@@ -503,7 +540,24 @@ namespace paac {
 // 1 us of the best everywhere except the entries below; anything else (other archs, larger batches) keeps the
 // heuristics.
 void default_tuning(paac_ctx* c) {
-  if (c->cfg.arch != PAAC_ARCH_NATURE || c->max_batch > 512) return;
+  if (c->cfg.arch != PAAC_ARCH_NATURE) return;
+  if (c->max_batch > 2048) return;   // size heuristics (measured better than the 1536-row table at 2688 rows)
+  if (c->max_batch > 512) {
+    // TUNE_N=256 tools/tune_gemm.py (256 envs x t_max 5: 1536-row training forward, 1280-row backward; the 256-row
+    // acting batch shares class 1).  At these sizes the K loops dominate and the split-bf16 path wins for most ops.
+    c->tune[OP_CONV1_FWD][1] = Tune{kExactBf16 + 11, 0, -1};
+    c->tune[OP_CONV2_FWD][1] = Tune{kSplitBf16 + 11, 0, -1};
+    c->tune[OP_CONV3_FWD][1] = Tune{kSplitBf16 + 10, 0, -1};
+    c->tune[OP_FC_FWD][1] = Tune{kSplitBf16 + 4, 4, -1};
+    c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
+    c->tune[OP_FC_DGRAD][1] = Tune{kSplitBf16 + 10, 0, -1};
+    c->tune[OP_CONV3_WGRAD][1] = Tune{kSplitBf16 + 1, 48, 2};
+    c->tune[OP_CONV3_DGRAD][1] = Tune{kSplitBf16 + 10, 0, -1};
+    c->tune[OP_CONV2_WGRAD][1] = Tune{kSplitBf16 + 3, 32, 2};
+    c->tune[OP_CONV2_DGRAD][1] = Tune{10, 0, 0};
+    c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 2, 64, 2};
+    return;
+  }
   // tools/tune_gemm.py on MI355X, 32 envs x t_max 5: acting batch 32 (class 0); training forward over 192 rows and
   // backward over 160 (class 1)
   c->tune[OP_CONV1_FWD][0] = Tune{kExactBf16 + 4, 0, -1};

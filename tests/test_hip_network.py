@@ -258,3 +258,46 @@ def test_conv1_exact_bf16_path(B, fwd_cfg, wgrad_cfg):
     for name in ("conv1_weights", "conv1_biases"):
         scale = max(np.abs(g_ref[name]).max(), 1e-6)
         assert np.abs(g_new[name] - g_ref[name]).max() / scale < 2e-5, name
+
+
+@pytest.mark.parametrize("arch,A,B,cfg_fwd,cfg_dgrad,cfg_wgrad", [("NATURE", 4, 160, 204, 202, 200), ("NATURE", 6, 32, 200, 201, 201),
+                                                                  ("NIPS", 6, 72, 207, 203, 203), ("NATURE", 4, 45, 211, 209, 208)])
+def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
+    """Every contraction on the six-product split-bf16 path (dmm.h: XB = 2): the same parity bars as the fp32 MFMA
+    path -- logits / values within 1e-4, gradients within 1e-4 of the float64 oracle."""
+    from paac_amd import hip_ops, _lib
+    params, states, idx, y, adv = make_case(arch, A, B, seed=9)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+    cls = 1 if B > 64 else 0
+    for op in (1, 2, 3):
+        _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, op, cls, cfg_fwd, 8 if op == 3 else 0, -1), "set_tuning")
+    for op in (5, 7, 9):
+        _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, op, cls, cfg_dgrad, 0, -1), "set_tuning")
+    for op in (4, 6, 8):
+        _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, op, cls, cfg_wgrad, 1 if op == 4 else 16, -1), "set_tuning")
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    logits = torch.zeros((B, A), device="cuda")
+    values = torch.zeros((B,), device="cuda")
+    ctx.forward(p, s, logits, None, values)
+    ref = onet.forward(params, states, arch, dtype=np.float64, keep=True)
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
+    nconv = 3 if arch == "NATURE" else 2
+    for i in range(nconv):
+        got = ctx.debug_activation(i + 1, B).cpu().numpy()
+        assert np.abs(got - ref["cache"]["a%d" % (i + 1)].reshape(-1)).max() < 2e-5
+    grad = torch.zeros(ctx.layout["total"], device="cuda")
+    ctx.loss_backward(p, s, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(adv).cuda(), 0.02,
+                      grad)
+    torch.cuda.synchronize()
+    masks = {"a%d" % (i + 1): ctx.debug_activation(i + 1, B).cpu().numpy() > 0 for i in range(nconv)}
+    masks["h"] = ctx.debug_activation(4, B).cpu().numpy() > 0
+    L, g_ref = onet.loss_and_grads(params, states, np.eye(A)[idx], y, adv, 0.02, arch, dtype=np.float64, relu_masks=masks)
+    got = unflatten(ctx, grad)
+    gn_ref = onet.global_norm(g_ref)
+    for name, want in g_ref.items():
+        err = np.abs(got[name] - want).max()
+        scale = max(np.abs(want).max(), 1e-3 * gn_ref)
+        assert err / scale < 1e-4, "%s: max abs err %g (scale %g)" % (name, err, scale)
+    ctx.close()

@@ -66,18 +66,20 @@ def candidates(op, cls):
         out = [(c, 0, -1) for c in range(13)]
         if op == 0:
             out += [(100 + c, 0, -1) for c in range(13)]      # conv1 on the exact-bf16 path
+        else:
+            out += [(200 + c, 0, -1) for c in range(13)]      # six-product split-bf16 path
     elif op == 3:
-        for c in range(13):
+        for c in list(range(13)) + [200 + c for c in range(13)]:
             for ks in (1, 2, 4, 8):
                 out.append((c, ks, -1))
                 if ks == 8:
                     out.append((c, ks, 2))
     elif fam == "dgrad":
-        out = [(c, 0, x) for c in range(12) for x in (-1, 0, 1)]
+        out = [(c, 0, x) for c in list(range(12)) + [200 + c for c in range(12)] for x in (-1, 0, 1)]
     elif op == 4:
-        out = [(c, 1, x) for c in range(9) for x in (-1, 0)]
+        out = [(c, 1, x) for c in list(range(9)) + [200 + c for c in range(9)] for x in (-1, 0)]
     else:
-        cfgs = [0, 1, 2, 3, 6, 7, 8, 100, 101, 102, 103, 106, 107, 108] if op == 10 else range(9)
+        cfgs = [0, 1, 2, 3, 6, 7, 8, 100, 101, 102, 103, 106, 107, 108] if op == 10 else list(range(9)) + [200 + c for c in range(9)]
         for c in cfgs:
             for ks in (8, 16, 32, 48, 64):
                 out.append((c, ks, -1)); out.append((c, ks, 2))
