@@ -6,11 +6,12 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(n):
     n = re.sub(r'paac::', '', n)
-    m = re.search(r'dmm_kernel<Dmm<Geom<([0-9, ]+)>, (true|false), (\d), (\d), (\d), (\d), (\d), (\d), (\d), (\d+), (\d), (true|false), (\d)> ?>', n)
+    m = re.search(r'dmm_kernel<Dmm<Geom<([0-9, ]+)>, (true|false), (\d), (\d), (\d), (\d), (\d), (\d), (\d), (\d+), (\d), (true|false), (\d)(?:, (\d))?> ?>', n)
     if m:
-        return 'dmm<G%s u8=%s ap%s bp%s T%sx%s W%s,%s,%s epi%s bias=%s pf%s>' % (
+        return 'dmm<G%s u8=%s ap%s bp%s T%sx%s W%s,%s,%s epi%s bias=%s pf%s%s>' % (
             m.group(1).replace(' ', ''), m.group(2)[0], m.group(3), m.group(4), m.group(5), m.group(6), m.group(7), m.group(8),
-            m.group(9), m.group(11), m.group(12)[0], m.group(13))
+            m.group(9), m.group(11), m.group(12)[0], m.group(13),
+            {None: "", "0": "", "1": " bf16-exact", "2": " bf16-split"}[m.group(14)])
     return n.split('(')[0][:70]
 
 # 1. rocprofv3 --kernel-trace --stats summary (verbatim csv) + one-cycle timeline
