@@ -1,154 +1,7 @@
-// Actor-critic network of the PAAC hot path on gfx950: forward, loss, backward.
-//   networks.py:100-169 (trunk), policy_v_network.py:6-57 (heads + loss), and the gradient graph
-//   optimizer.compute_gradients(loss) builds from them (actor_learner.py:44).
-// Layout contract: activations NHWC fp32, conv weights HWIO, fc weights [in,out], flatten in HWC order
-// (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
-#include <stdlib.h>
-
-#include "dmm.h"
-#include "heads.h"
+// Backward half of the actor-critic network (see net_fwd.hip): dgrad / wgrad launches, slab finalize, launch tuning.
+#include "net_common.h"
 
 namespace paac {
-
-// ---------------------------------------------------------------------------------------------
-// Compile-time network descriptions.
-struct NatureNet {
-  static constexpr int NCONV = 3, C1 = 32, C2 = 64, C3 = 64, H = 512, FLAT = 3136;
-  using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
-  using G2 = Geom<20, 20, 32, 9, 9, 2, 0, 0, 4, 4>;
-  using G3 = Geom<9, 9, 64, 7, 7, 1, 0, 0, 3, 3>;
-  using GFC = Geom<1, 1, 3136, 1, 1, 1, 0, 0, 1, 1>;   // rows of the flattened last conv output
-  using GFCH = Geom<1, 1, 512, 1, 1, 1, 0, 0, 1, 1>;   // rows of dH
-  using G3D = Geom<7, 7, 64, 9, 9, 1, 2, 2, 3, 3>;     // conv3 dgrad: full correlation over dY3
-  using G2D = Geom<9, 9, 64, 10, 10, 1, 1, 1, 2, 2>;   // conv2 dgrad, one output parity class
-};
-struct NipsNet {
-  static constexpr int NCONV = 2, C1 = 16, C2 = 32, C3 = 32, H = 256, FLAT = 2592;
-  using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
-  using G2 = Geom<20, 20, 16, 9, 9, 2, 0, 0, 4, 4>;
-  using G3 = Geom<9, 9, 32, 7, 7, 1, 0, 0, 3, 3>;      // unused
-  using GFC = Geom<1, 1, 2592, 1, 1, 1, 0, 0, 1, 1>;
-  using GFCH = Geom<1, 1, 256, 1, 1, 1, 0, 0, 1, 1>;
-  using G3D = Geom<7, 7, 32, 9, 9, 1, 2, 2, 3, 3>;     // unused
-  using G2D = Geom<9, 9, 32, 10, 10, 1, 1, 1, 2, 2>;
-};
-
-constexpr int W_SPLITS_MAX = 64;
-
-#ifdef PAAC_DMM_STAMPS
-unsigned long long* g_stamps = nullptr;   // diagnostic build: the `which`-th dmm launch after the call is stamped
-int g_stamp_which = -1, g_stamp_calls = 0;
-extern "C" void paac_debug_set_heads_stamps(unsigned long long* p);
-extern "C" void paac_debug_set_stamps(unsigned long long* p, int which) {
-  g_stamps = p;
-  g_stamp_which = which;
-  g_stamp_calls = 0;
-}
-#endif
-
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
-static GemmArgs make_args(const void* A, size_t a_bytes, const float* B, size_t b_bytes, float* out, const float* aux,
-                          int M, int N, int K, int ldb, int ldo) {
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = A; g.B = B; g.out = out; g.aux = aux;
-  g.a_bytes = (unsigned)(a_bytes < 0x7FFFFFF0ull ? a_bytes : 0x7FFFFFF0ull);
-  g.b_bytes = (unsigned)(b_bytes < 0x7FFFFFF0ull ? b_bytes : 0x7FFFFFF0ull);
-  g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldo = ldo;
-  g.slab_rows = M;
-#ifdef PAAC_DMM_STAMPS
-  g.stamps = (g_stamp_calls++ == g_stamp_which) ? g_stamps : nullptr;
-#endif
-  return g;
-}
-
-// blockIdx.z split of K so that the launch has about `target_waves` waves.
-static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int target_waves = 1024) {
-  long s = (target_waves + tiles * wk - 1) / (tiles * wk);
-  if (s > max_split) s = max_split;
-  if (s > ngroups / wk) s = ngroups / wk;
-  if (s < 1) s = 1;
-  const int per = (int)((ngroups + s * wk - 1) / (s * wk));     // groups per (z, wk) part
-  s = (ngroups + (long)per * wk - 1) / ((long)per * wk);         // drop empty tail slabs
-  return (int)s;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Launch configurations.  Each GEMM family has a small table of (tiles per wave, waves per workgroup, K split over
-// waves, prefetch depth) instantiations; a Tune record (per op and batch class, set from measured sweeps --
-// tools/tune_gemm.py -- or left at cfg = -1 for the size heuristic) picks one, plus the blockIdx.z K split and the
-// XCD-tied grid dimension.
-//                      id TM NWM WK PF
-#define PAAC_FWD_CFGS(X) X(0, 1, 1, 8, 5) X(1, 1, 1, 4, 5) X(2, 2, 1, 8, 3) X(3, 2, 1, 4, 3) X(4, 2, 2, 2, 2) \
-                         X(5, 2, 4, 1, 2) X(6, 1, 2, 4, 4) X(7, 2, 2, 4, 2) X(8, 2, 2, 1, 3) X(9, 1, 4, 1, 4) \
-                         X(10, 4, 1, 2, 2) X(11, 4, 2, 1, 2) X(12, 2, 1, 2, 3)
-#define PAAC_DGRAD_CFGS(X) X(0, 1, 1, 8, 4) X(1, 2, 1, 4, 4) X(2, 2, 2, 2, 3) X(3, 2, 4, 1, 2) X(4, 1, 1, 4, 4) \
-                           X(5, 2, 1, 8, 3) X(6, 1, 2, 4, 4) X(7, 2, 2, 1, 3) X(8, 1, 4, 1, 4) X(9, 4, 1, 2, 2)  \
-                           X(10, 4, 2, 1, 2) X(11, 2, 1, 2, 3)
-//                        id TM WK PF
-#define PAAC_WGRAD_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(2, 4, 8, 2) X(3, 4, 4, 3) X(4, 2, 4, 3) X(5, 2, 8, 3) X(6, 4, 1, 3) \
-                           X(7, 4, 1, 4) X(8, 4, 2, 3)
-constexpr int kFwdCfgs = 13, kDgradCfgs = 12, kWgradCfgs = 9;
-constexpr int kExactBf16 = 100;   // cfg ids from here on: the same table entry on the exact-bf16 path (u8 operand only)
-constexpr int kSplitBf16 = 200;   // ... on the six-product split-bf16 path (fp32 operands; dmm.h: XB = 2)
-constexpr int split_pf(int pf) { return pf > 2 ? 2 : pf; }   // a stage is two K groups there: shallower ring
-
-// Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
-template <class G, bool U8, int NDIM, int EPI>
-static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
-  constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
-  int cfg = t.cfg, ksplit = 1, xcd = t.xcd;
-  if constexpr (EPI == EPI_SLAB) {
-    ksplit = t.ksplit > 0 ? t.ksplit : 0;
-    if (ksplit <= 0) {   // heuristic: fill ~768 waves
-      const long tiles = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN));
-      ksplit = pick_ksplit(tiles, 4, (g.K + 15) / 16, FC_SPLITS_MAX, 768);
-    }
-    if (ksplit > FC_SPLITS_MAX) ksplit = FC_SPLITS_MAX;
-  }
-  if (cfg < 0) {
-    const long w = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN)) * ksplit;
-    cfg = (w <= 256) ? 0 : (w <= 1024) ? 3 : (w <= 4096) ? 4 : 5;
-    if (U8) cfg += kExactBf16;   // the u8 operand always takes the exact-bf16 path (faster at every size measured)
-    xcd = -1;
-  }
-  if constexpr (U8) {
-    if (cfg >= kExactBf16) {   // conv1 on the bf16 MFMA with exactly split weights (dmm.h: XB), same tile table
-      switch (cfg - kExactBf16) {
-#define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF, 1>>(g, ksplit, ksplit, xcd, s); break;
-        PAAC_FWD_CFGS(X)
-#undef X
-        default: break;
-      }
-      return ksplit;
-    }
-  }
-  if constexpr (!U8) {
-    if (cfg >= kSplitBf16) {
-      switch (cfg - kSplitBf16) {
-#define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, split_pf(PF), 2>>(g, ksplit, ksplit, xcd, s); break;
-        PAAC_FWD_CFGS(X)
-#undef X
-        default: break;
-      }
-      return ksplit;
-    }
-  }
-  switch (cfg) {
-#define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF>>(g, ksplit, ksplit, xcd, s); break;
-    PAAC_FWD_CFGS(X)
-#undef X
-    default: break;
-  }
-  return ksplit;
-}
 
 // dgrad: A = FRAG_K patches of dY, B = FRAG_K taps of W^T.
 template <int NDIM>
@@ -177,12 +30,11 @@ static void launch_dgrad(const GemmArgs& g, int zdim, Tune t, hipStream_t s) {
   if (cfg >= kSplitBf16) {
     switch (cfg - kSplitBf16) {
 #define X(id, TM, NWM, WK, PF) \
-  case id: launch_dmm<DgradBody<G, NDIM, BCO, EPI, TM, NWM, WK, split_pf(PF), 2>>(g, zdim, 1, xcd, s); break;
-      PAAC_DGRAD_CFGS(X)
+  case id: launch_dmm<DgradBody<G, NDIM, BCO, EPI, TM, NWM, WK, split_pf(PF), 2>>(g, zdim, 1, xcd, s); return;
+      PAAC_DGRAD_SPLIT_CFGS(X)
 #undef X
-      default: break;
+      default: cfg -= kSplitBf16; break;
     }
-    return;
   }
   switch (cfg) {
 #define X(id, TM, NWM, WK, PF) \
@@ -251,12 +103,11 @@ static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s)
     if (cfg >= kSplitBf16) {
       switch (cfg - kSplitBf16) {
 #define X(id, TM, WK, PF) \
-  case id: launch_dmm<WgradBody<G, U8, NDIM, TM, WK, split_pf(PF), 2>>(g, ks, ks, xcd, s); break;
-        PAAC_WGRAD_CFGS(X)
+  case id: launch_dmm<WgradBody<G, U8, NDIM, TM, WK, split_pf(PF), 2>>(g, ks, ks, xcd, s); return ks;
+        PAAC_WGRAD_SPLIT_CFGS(X)
 #undef X
-        default: break;
+        default: cfg -= kSplitBf16; break;
       }
-      return ks;
     }
   }
   switch (cfg) {
@@ -312,65 +163,6 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinalizeArgs a
     for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], off, 64);
   }
   if (live && r == 0) *reinterpret_cast<f32x4*>(sg.dst + i) = v;
-}
-
-// ---------------------------------------------------------------------------------------------
-template <class NT>
-static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
-                        float* probs, float* values, const PhiloxArgs& ph, hipStream_t s) {
-  const paac_layout& L = ctx->layout;
-  Workspace& W = ctx->ws[wsi];
-  ctx->last_ws = wsi;
-  const int cls = batch > 64 ? 1 : 0;
-  const int A = ctx->cfg.num_actions;
-  int t = 0;
-  const float* w1 = params + L.offset[t++];
-  const float* b1 = params + L.offset[t++];
-  const float* w2 = params + L.offset[t++];
-  const float* b2 = params + L.offset[t++];
-  const float* w3 = nullptr;
-  const float* b3 = nullptr;
-  if constexpr (NT::NCONV == 3) {
-    w3 = params + L.offset[t++];
-    b3 = params + L.offset[t++];
-  }
-  const float* wf = params + L.offset[t++];
-  const float* bf = params + L.offset[t++];
-  const float* wa = params + L.offset[t++];
-  const float* ba = params + L.offset[t++];
-  const float* wc = params + L.offset[t++];
-  const float* bc = params + L.offset[t++];
-
-  {
-    ProfScope ps(ctx, F_CONV1_FWD, batch, s);
-    GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)256 * NT::C1 * 4, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
-    launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
-  }
-  {
-    ProfScope ps(ctx, F_CONV2_FWD, batch, s);
-    GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
-    launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
-  }
-  const float* last = W.act[1];
-  if constexpr (NT::NCONV == 3) {
-    ProfScope ps(ctx, F_CONV3_FWD, batch, s);
-    GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
-    launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);
-    last = W.act[2];
-  }
-  int splits = 1;
-  {
-    ProfScope ps(ctx, F_FC_FWD, batch, s);
-    GemmArgs g = make_args(last, (size_t)batch * NT::FLAT * 4, wf, (size_t)NT::FLAT * NT::H * 4, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
-    g.slab_rows = batch;
-    splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
-  }
-  {
-    ProfScope ps(ctx, F_HEADS_FWD, batch, s);
-    launch_heads_fwd<NT::H>(A, dim3(batch), s, (const float*)W.fc_slab, splits, (long)batch * NT::H, bf, wa, ba, wc, bc,
-                            A, W.h, W.logits, W.probs, W.values, logits, probs, values, ph);
-  }
-  return 0;
 }
 
 // phase: 0 = whole backward; 1 = heads + fc (gradients of fc_w .. critic_b, the contiguous tail of the flat
@@ -487,30 +279,6 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   return 0;
 }
 
-int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,
-                   float* probs, float* values, hipStream_t s) {
-  PhiloxArgs ph;
-  memset(&ph, 0, sizeof(ph));
-  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
-  return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
-}
-
-int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
-                          float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
-                          uint32_t env_offset, int32_t* actions, hipStream_t s) {
-  PhiloxArgs ph;
-  ph.enabled = 1;
-  ph.seed = seed;
-  ph.step_base = step_base;
-  ph.step_off = step_off;
-  ph.env_offset = env_offset;
-  ph.actions = actions;
-  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
-  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
-}
-
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s) {
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
@@ -518,19 +286,12 @@ int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, c
   return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, s);
 }
 
-#ifdef PAAC_DMM_STAMPS
-extern "C" void paac_debug_set_heads_stamps(unsigned long long* p) {
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_dev), &p, sizeof(p));
-}
-#endif
-
 int64_t wslab_floats_needed(int arch) {
   if (arch == PAAC_ARCH_NATURE)
     return (int64_t)W_SPLITS_MAX * ((NatureNet::G3::FEATS + 1) * NatureNet::C3 + (NatureNet::G2::FEATS + 1) * NatureNet::C2 +
                                     257 * NatureNet::C1);
   return (int64_t)W_SPLITS_MAX * ((NipsNet::G2::FEATS + 1) * NipsNet::C2 + 257 * NipsNet::C1);
 }
-int fc_splits_max() { return FC_SPLITS_MAX; }
 
 }  // namespace paac
 
@@ -576,3 +337,4 @@ void default_tuning(paac_ctx* c) {
   c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 2, 64, 2};
 }
 }  // namespace paac
+

@@ -1,0 +1,98 @@
+// Shared by net_fwd.hip and net_bwd.hip (two translation units so that the template instantiations compile in
+// parallel): network geometries, GEMM argument packing, launch configuration tables.
+#pragma once
+#include <stdlib.h>
+
+#include "dmm.h"
+#include "heads.h"
+
+namespace paac {
+
+// ---------------------------------------------------------------------------------------------
+// Compile-time network descriptions.
+struct NatureNet {
+  static constexpr int NCONV = 3, C1 = 32, C2 = 64, C3 = 64, H = 512, FLAT = 3136;
+  using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
+  using G2 = Geom<20, 20, 32, 9, 9, 2, 0, 0, 4, 4>;
+  using G3 = Geom<9, 9, 64, 7, 7, 1, 0, 0, 3, 3>;
+  using GFC = Geom<1, 1, 3136, 1, 1, 1, 0, 0, 1, 1>;   // rows of the flattened last conv output
+  using GFCH = Geom<1, 1, 512, 1, 1, 1, 0, 0, 1, 1>;   // rows of dH
+  using G3D = Geom<7, 7, 64, 9, 9, 1, 2, 2, 3, 3>;     // conv3 dgrad: full correlation over dY3
+  using G2D = Geom<9, 9, 64, 10, 10, 1, 1, 1, 2, 2>;   // conv2 dgrad, one output parity class
+};
+struct NipsNet {
+  static constexpr int NCONV = 2, C1 = 16, C2 = 32, C3 = 32, H = 256, FLAT = 2592;
+  using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
+  using G2 = Geom<20, 20, 16, 9, 9, 2, 0, 0, 4, 4>;
+  using G3 = Geom<9, 9, 32, 7, 7, 1, 0, 0, 3, 3>;      // unused
+  using GFC = Geom<1, 1, 2592, 1, 1, 1, 0, 0, 1, 1>;
+  using GFCH = Geom<1, 1, 256, 1, 1, 1, 0, 0, 1, 1>;
+  using G3D = Geom<7, 7, 32, 9, 9, 1, 2, 2, 3, 3>;     // unused
+  using G2D = Geom<9, 9, 32, 10, 10, 1, 1, 1, 2, 2>;
+};
+
+constexpr int W_SPLITS_MAX = 64;
+
+#ifdef PAAC_DMM_STAMPS
+extern unsigned long long* g_stamps;   // diagnostic build: the `which`-th dmm launch after the call is stamped
+extern int g_stamp_which, g_stamp_calls;
+#endif
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static GemmArgs make_args(const void* A, size_t a_bytes, const float* B, size_t b_bytes, float* out, const float* aux,
+                          int M, int N, int K, int ldb, int ldo) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.out = out; g.aux = aux;
+  g.a_bytes = (unsigned)(a_bytes < 0x7FFFFFF0ull ? a_bytes : 0x7FFFFFF0ull);
+  g.b_bytes = (unsigned)(b_bytes < 0x7FFFFFF0ull ? b_bytes : 0x7FFFFFF0ull);
+  g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldo = ldo;
+  g.slab_rows = M;
+#ifdef PAAC_DMM_STAMPS
+  g.stamps = (g_stamp_calls++ == g_stamp_which) ? g_stamps : nullptr;
+#endif
+  return g;
+}
+
+// blockIdx.z split of K so that the launch has about `target_waves` waves.
+static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int target_waves = 1024) {
+  long s = (target_waves + tiles * wk - 1) / (tiles * wk);
+  if (s > max_split) s = max_split;
+  if (s > ngroups / wk) s = ngroups / wk;
+  if (s < 1) s = 1;
+  const int per = (int)((ngroups + s * wk - 1) / (s * wk));     // groups per (z, wk) part
+  s = (ngroups + (long)per * wk - 1) / ((long)per * wk);         // drop empty tail slabs
+  return (int)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch configurations.  Each GEMM family has a small table of (tiles per wave, waves per workgroup, K split over
+// waves, prefetch depth) instantiations; a Tune record (per op and batch class, set from measured sweeps --
+// tools/tune_gemm.py -- or left at cfg = -1 for the size heuristic) picks one, plus the blockIdx.z K split and the
+// XCD-tied grid dimension.
+//                      id TM NWM WK PF
+#define PAAC_FWD_CFGS(X) X(0, 1, 1, 8, 5) X(1, 1, 1, 4, 5) X(2, 2, 1, 8, 3) X(3, 2, 1, 4, 3) X(4, 2, 2, 2, 2) \
+                         X(5, 2, 4, 1, 2) X(6, 1, 2, 4, 4) X(7, 2, 2, 4, 2) X(8, 2, 2, 1, 3) X(9, 1, 4, 1, 4) \
+                         X(10, 4, 1, 2, 2) X(11, 4, 2, 1, 2) X(12, 2, 1, 2, 3)
+#define PAAC_DGRAD_CFGS(X) X(0, 1, 1, 8, 4) X(1, 2, 1, 4, 4) X(2, 2, 2, 2, 3) X(3, 2, 4, 1, 2) X(4, 1, 1, 4, 4) \
+                           X(5, 2, 1, 8, 3) X(6, 1, 2, 4, 4) X(7, 2, 2, 1, 3) X(8, 1, 4, 1, 4) X(9, 4, 1, 2, 2)  \
+                           X(10, 4, 2, 1, 2) X(11, 2, 1, 2, 3)
+//                        id TM WK PF
+#define PAAC_WGRAD_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(2, 4, 8, 2) X(3, 4, 4, 3) X(4, 2, 4, 3) X(5, 2, 8, 3) X(6, 4, 1, 3) \
+                           X(7, 4, 1, 4) X(8, 4, 2, 3)
+// the entries also instantiated on the split-bf16 path (ids + kSplitBf16); an id outside falls back to its fp32 form
+#define PAAC_FWD_SPLIT_CFGS(X) X(1, 1, 1, 4, 5) X(4, 2, 2, 2, 2) X(7, 2, 2, 4, 2) X(10, 4, 1, 2, 2) X(11, 4, 2, 1, 2) \
+                               X(12, 2, 1, 2, 3)
+#define PAAC_DGRAD_SPLIT_CFGS(X) X(1, 2, 1, 4, 4) X(5, 2, 1, 8, 3) X(9, 4, 1, 2, 2) X(10, 4, 2, 1, 2) X(11, 2, 1, 2, 3)
+#define PAAC_WGRAD_SPLIT_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(3, 4, 4, 3)
+constexpr int kFwdCfgs = 13, kDgradCfgs = 12, kWgradCfgs = 9;
+constexpr int kExactBf16 = 100;   // cfg ids from here on: the same table entry on the exact-bf16 path (u8 operand only)
+constexpr int kSplitBf16 = 200;   // ... on the six-product split-bf16 path (fp32 operands; dmm.h: XB = 2)
+constexpr int split_pf(int pf) { return pf > 2 ? 2 : pf; }   // a stage is two K groups there: shallower ring
+
+
+}  // namespace paac

@@ -1,0 +1,163 @@
+// Actor-critic network of the PAAC hot path on gfx950: forward, loss, backward.
+//   networks.py:100-169 (trunk), policy_v_network.py:6-57 (heads + loss), and the gradient graph
+//   optimizer.compute_gradients(loss) builds from them (actor_learner.py:44).
+// Layout contract: activations NHWC fp32, conv weights HWIO, fc weights [in,out], flatten in HWC order
+// (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
+#include "net_common.h"
+
+namespace paac {
+
+#ifdef PAAC_DMM_STAMPS
+unsigned long long* g_stamps = nullptr;
+int g_stamp_which = -1, g_stamp_calls = 0;
+extern "C" void paac_debug_set_stamps(unsigned long long* p, int which) {
+  g_stamps = p;
+  g_stamp_which = which;
+  g_stamp_calls = 0;
+}
+#endif
+
+// Forward conv/fc: A = FRAG_K patches, B = FRAG_MN weights [K,N].  N per wave = 16*VN.
+template <class G, bool U8, int NDIM, int EPI>
+static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
+  constexpr int VN = (NDIM % 64 == 0) ? 4 : (NDIM % 32 == 0) ? 2 : 1;
+  int cfg = t.cfg, ksplit = 1, xcd = t.xcd;
+  if constexpr (EPI == EPI_SLAB) {
+    ksplit = t.ksplit > 0 ? t.ksplit : 0;
+    if (ksplit <= 0) {   // heuristic: fill ~768 waves
+      const long tiles = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN));
+      ksplit = pick_ksplit(tiles, 4, (g.K + 15) / 16, FC_SPLITS_MAX, 768);
+    }
+    if (ksplit > FC_SPLITS_MAX) ksplit = FC_SPLITS_MAX;
+  }
+  if (cfg < 0) {
+    const long w = (long)((g.M + 15) / 16) * ((g.N + 16 * VN - 1) / (16 * VN)) * ksplit;
+    cfg = (w <= 256) ? 0 : (w <= 1024) ? 3 : (w <= 4096) ? 4 : 5;
+    if (U8) cfg += kExactBf16;   // the u8 operand always takes the exact-bf16 path (faster at every size measured)
+    xcd = -1;
+  }
+  if constexpr (U8) {
+    if (cfg >= kExactBf16) {   // conv1 on the bf16 MFMA with exactly split weights (dmm.h: XB), same tile table
+      switch (cfg - kExactBf16) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF, 1>>(g, ksplit, ksplit, xcd, s); break;
+        PAAC_FWD_CFGS(X)
+#undef X
+        default: break;
+      }
+      return ksplit;
+    }
+  }
+  if constexpr (!U8) {
+    if (cfg >= kSplitBf16) {
+      switch (cfg - kSplitBf16) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, split_pf(PF), 2>>(g, ksplit, ksplit, xcd, s); return ksplit;
+        PAAC_FWD_SPLIT_CFGS(X)
+#undef X
+        default: cfg -= kSplitBf16; break;   // not instantiated on the split path: its fp32 form
+      }
+    }
+  }
+  switch (cfg) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, VN, NWM, 1, WK, 1, EPI, false, PF>>(g, ksplit, ksplit, xcd, s); break;
+    PAAC_FWD_CFGS(X)
+#undef X
+    default: break;
+  }
+  return ksplit;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class NT>
+static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
+                        float* probs, float* values, const PhiloxArgs& ph, hipStream_t s) {
+  const paac_layout& L = ctx->layout;
+  Workspace& W = ctx->ws[wsi];
+  ctx->last_ws = wsi;
+  const int cls = batch > 64 ? 1 : 0;
+  const int A = ctx->cfg.num_actions;
+  int t = 0;
+  const float* w1 = params + L.offset[t++];
+  const float* b1 = params + L.offset[t++];
+  const float* w2 = params + L.offset[t++];
+  const float* b2 = params + L.offset[t++];
+  const float* w3 = nullptr;
+  const float* b3 = nullptr;
+  if constexpr (NT::NCONV == 3) {
+    w3 = params + L.offset[t++];
+    b3 = params + L.offset[t++];
+  }
+  const float* wf = params + L.offset[t++];
+  const float* bf = params + L.offset[t++];
+  const float* wa = params + L.offset[t++];
+  const float* ba = params + L.offset[t++];
+  const float* wc = params + L.offset[t++];
+  const float* bc = params + L.offset[t++];
+
+  {
+    ProfScope ps(ctx, F_CONV1_FWD, batch, s);
+    GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)256 * NT::C1 * 4, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
+    launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
+  }
+  {
+    ProfScope ps(ctx, F_CONV2_FWD, batch, s);
+    GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
+    launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
+  }
+  const float* last = W.act[1];
+  if constexpr (NT::NCONV == 3) {
+    ProfScope ps(ctx, F_CONV3_FWD, batch, s);
+    GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
+    launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);
+    last = W.act[2];
+  }
+  int splits = 1;
+  {
+    ProfScope ps(ctx, F_FC_FWD, batch, s);
+    GemmArgs g = make_args(last, (size_t)batch * NT::FLAT * 4, wf, (size_t)NT::FLAT * NT::H * 4, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
+    g.slab_rows = batch;
+    splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
+  }
+  {
+    ProfScope ps(ctx, F_HEADS_FWD, batch, s);
+    launch_heads_fwd<NT::H>(A, dim3(batch), s, (const float*)W.fc_slab, splits, (long)batch * NT::H, bf, wa, ba, wc, bc,
+                            A, W.h, W.logits, W.probs, W.values, logits, probs, values, ph);
+  }
+  return 0;
+}
+
+int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,
+                   float* probs, float* values, hipStream_t s) {
+  PhiloxArgs ph;
+  memset(&ph, 0, sizeof(ph));
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
+  return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
+}
+
+int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                          float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
+                          uint32_t env_offset, int32_t* actions, hipStream_t s) {
+  PhiloxArgs ph;
+  ph.enabled = 1;
+  ph.seed = seed;
+  ph.step_base = step_base;
+  ph.step_off = step_off;
+  ph.env_offset = env_offset;
+  ph.actions = actions;
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
+  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
+}
+
+#ifdef PAAC_DMM_STAMPS
+extern "C" void paac_debug_set_heads_stamps(unsigned long long* p) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_dev), &p, sizeof(p));
+}
+#endif
+
+int fc_splits_max() { return FC_SPLITS_MAX; }
+
+}  // namespace paac

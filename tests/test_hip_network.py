@@ -260,11 +260,13 @@ def test_conv1_exact_bf16_path(B, fwd_cfg, wgrad_cfg):
         assert np.abs(g_new[name] - g_ref[name]).max() / scale < 2e-5, name
 
 
-@pytest.mark.parametrize("arch,A,B,cfg_fwd,cfg_dgrad,cfg_wgrad", [("NATURE", 4, 160, 204, 202, 200), ("NATURE", 6, 32, 200, 201, 201),
-                                                                  ("NIPS", 6, 72, 207, 203, 203), ("NATURE", 4, 45, 211, 209, 208)])
+@pytest.mark.parametrize("arch,A,B,cfg_fwd,cfg_dgrad,cfg_wgrad", [("NATURE", 4, 160, 204, 205, 200), ("NATURE", 6, 32, 201, 201, 201),
+                                                                  ("NIPS", 6, 72, 207, 210, 203), ("NATURE", 4, 45, 211, 209, 203),
+                                                                  ("NATURE", 4, 192, 212, 211, 201), ("NIPS", 18, 33, 210, 209, 200)])
 def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
-    """Every contraction on the six-product split-bf16 path (dmm.h: XB = 2): the same parity bars as the fp32 MFMA
-    path -- logits / values within 1e-4, gradients within 1e-4 of the float64 oracle."""
+    """Every contraction on the six-product split-bf16 path (dmm.h: XB = 2; the ids are entries of
+    PAAC_*_SPLIT_CFGS, i.e. really instantiated there): the same parity bars as the fp32 MFMA path -- logits / values
+    within 1e-4, gradients within 1e-4 of the float64 oracle."""
     from paac_amd import hip_ops, _lib
     params, states, idx, y, adv = make_case(arch, A, B, seed=9)
     ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
