@@ -3,11 +3,11 @@
 In the reference a Network is a TensorFlow graph fragment; here it is a DESCRIPTION (architecture id, flat
 parameter layout) plus the flat fp32 parameter buffer in HBM.  The arithmetic -- u8->f32 * (1/255)
 (networks.py:115), VALID NHWC x HWIO convs + bias + ReLU (:12-21), HWC flatten (:6-9), fc + ReLU (:49-60),
-softmax head (:84-89) -- is executed by libpaac_hip.so (csrc/net.hip).  The attribute names the learner and
+softmax head (:84-89) -- is executed by libpaac_hip.so (csrc/net_fwd.hip, csrc/net_bwd.hip).  The attribute names the learner and
 test.py touch (`input_ph`, `output`, `init(checkpoint_folder, saver, session)`) are kept.
 
 New architectures: the reference lets users subclass Network and set `self.output`; here an architecture is a
-compiled kernel chain, so adding one means adding its geometry to csrc/net.hip (NatureNet / NipsNet) and an
+compiled kernel chain, so adding one means adding its geometry to csrc/net_common.h (NatureNet / NipsNet) and an
 entry in ARCH_IDS.
 """
 import glob

@@ -3,7 +3,7 @@
 Keeps the attribute names PAACLearner feeds and fetches (paac.py:20-23,140-142,157-160; actor_learner.py:44):
 `output_layer_pi`, `output_layer_v`, `critic_target_ph`, `adv_actor_ph`, `selected_action_ph`, `loss`.
 The maths (softmax head, linear critic, log(pi+1e-30), entropy, actor/critic means, loss = 5*(actor+critic))
-runs in csrc/net.hip: heads_fwd_kernel / heads_bwd_kernel.
+runs in csrc/heads.h: heads_fwd_kernel / heads_bwd_kernel.
 """
 import numpy as np
 

@@ -1,7 +1,7 @@
 """Coordinate-descent sweep of the GEMM launch configurations on the benchmark shapes (MI355X).
 Times the replayed forward (acting batch) and forward+backward (training batch) hipGraphs while changing one
 op's (cfg, ksplit, xcd) at a time through paac_debug_set_tuning; prints the best table as C++ for
-csrc/net.hip:default_tuning and as JSON (gpurun_out/tune.json)."""
+csrc/net_bwd.hip:default_tuning and as JSON (gpurun_out/tune.json)."""
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
