@@ -134,6 +134,33 @@ __device__ __forceinline__ f32x4 bloadv(__amdgpu_buffer_rsrc_t r, unsigned voff,
   }
 }
 
+// bf16 pair from the HIGH halves of two fp32 bit patterns (element 0 in the low half): one v_perm_b32.
+__device__ __forceinline__ unsigned pack_hi16(unsigned x0, unsigned x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+// Exact three-way bf16 split of 8 fp32 values: x = hi + mid + lo with 8 mantissa bits each (truncate, subtract,
+// repeat; every subtraction is exact).  4 VALU ops per value + 1.5 for the packing.
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+  unsigned xb[8], r1b[8], r2b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    xb[e] = __builtin_bit_cast(unsigned, x[e]);
+    const float r1 = x[e] - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);
+    r1b[e] = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, r1b[e] & 0xFFFF0000u);
+    r2b[e] = __builtin_bit_cast(unsigned, r2);
+  }
+  u32x4 hi, mid, lo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hi[q] = pack_hi16(xb[2 * q], xb[2 * q + 1]);
+    mid[q] = pack_hi16(r1b[2 * q], r1b[2 * q + 1]);
+    lo[q] = pack_hi16(r2b[2 * q], r2b[2 * q + 1]);
+  }
+  ph = __builtin_bit_cast(bf16x8, hi);
+  pm = __builtin_bit_cast(bf16x8, mid);
+  pl = __builtin_bit_cast(bf16x8, lo);
+}
+
 template <int V>
 __device__ __forceinline__ f32x4 loadv(const float* p) {
   if constexpr (V == 4) {
@@ -415,29 +442,6 @@ struct Dmm {
         }
       } else if constexpr (XB == 2) {
         // three bf16 planes per operand tile; element e = 4 gs + s of a lane's 8 is k = 4kq + s of group gs
-        auto split3 = [&](const float (&x)[8], bf16x8& ph, bf16x8& pm, bf16x8& pl) {
-          u32x4 hi, mid, lo;
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            unsigned h[2], m[2], l[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const unsigned xh = __builtin_bit_cast(unsigned, x[e + u]) & 0xFFFF0000u;
-              const float r1 = x[e + u] - __builtin_bit_cast(float, xh);
-              const unsigned xm = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-              const float r2 = r1 - __builtin_bit_cast(float, xm);
-              h[u] = xh >> 16;
-              m[u] = xm >> 16;
-              l[u] = __builtin_bit_cast(unsigned, r2) >> 16;
-            }
-            hi[e / 2] = h[0] | (h[1] << 16);
-            mid[e / 2] = m[0] | (m[1] << 16);
-            lo[e / 2] = l[0] | (l[1] << 16);
-          }
-          ph = __builtin_bit_cast(bf16x8, hi);
-          pm = __builtin_bit_cast(bf16x8, mid);
-          pl = __builtin_bit_cast(bf16x8, lo);
-        };
         bf16x8 ah[TM], am[TM], al[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -446,7 +450,7 @@ struct Dmm {
           for (int gs = 0; gs < 2; ++gs)
 #pragma unroll
             for (int s = 0; s < 4; ++s) x[4 * gs + s] = (AP == FRAG_K) ? fa[st][gs][i][s] : fa[st][gs][s][i];
-          split3(x, ah[i], am[i], al[i]);
+          split3_bf16(x, ah[i], am[i], al[i]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -456,7 +460,7 @@ struct Dmm {
 #pragma unroll
             for (int s = 0; s < 4; ++s) x[4 * gs + s] = (BP == FRAG_K) ? fb[st][gs][j][s] : fb[st][gs][s][j];
           bf16x8 bh, bm, bl;
-          split3(x, bh, bm, bl);
+          split3_bf16(x, bh, bm, bl);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {   // smallest terms first
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
@@ -481,44 +485,27 @@ struct Dmm {
           u32x4 w;
 #pragma unroll
           for (int gs = 0; gs < 2; ++gs) {
-            unsigned b[4];
+            unsigned f[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               // FRAG_K: the dword of tile i carries k = 4kq .. 4kq+3; FRAG_MN: dword s carries the 4 tiles of k = 4kq+s
               const unsigned byte = (AP == FRAG_K) ? (ua[st][gs][i] >> (8 * s)) & 255u : (ua[st][gs][s] >> (8 * i)) & 255u;
-              b[s] = __builtin_bit_cast(unsigned, (float)byte) >> 16;    // an integer < 256 is exact in bf16
+              f[s] = __builtin_bit_cast(unsigned, (float)byte);          // v_cvt_f32_ubyteN; an integer < 256 is exact in bf16
             }
-            w[2 * gs] = b[0] | (b[1] << 16);
-            w[2 * gs + 1] = b[2] | (b[3] << 16);
+            w[2 * gs] = pack_hi16(f[0], f[1]);
+            w[2 * gs + 1] = pack_hi16(f[2], f[3]);
           }
           a8[i] = __builtin_bit_cast(bf16x8, w);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          u32x4 hi, mid, lo;
+          float x[8];
 #pragma unroll
-          for (int gs = 0; gs < 2; ++gs) {
-            unsigned h[4], m[4], l[4];
+          for (int gs = 0; gs < 2; ++gs)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const float x = fb[st][gs][s][j];
-              const unsigned xh = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;      // top 8 mantissa bits (truncated)
-              const float r1 = x - __builtin_bit_cast(float, xh);                     // exact
-              const unsigned xm = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;     // next 8
-              const float r2 = r1 - __builtin_bit_cast(float, xm);                    // exact, <= 8 bits left
-              h[s] = xh >> 16;
-              m[s] = xm >> 16;
-              l[s] = __builtin_bit_cast(unsigned, r2) >> 16;
-            }
-            hi[2 * gs] = h[0] | (h[1] << 16);
-            hi[2 * gs + 1] = h[2] | (h[3] << 16);
-            mid[2 * gs] = m[0] | (m[1] << 16);
-            mid[2 * gs + 1] = m[2] | (m[3] << 16);
-            lo[2 * gs] = l[0] | (l[1] << 16);
-            lo[2 * gs + 1] = l[2] | (l[3] << 16);
-          }
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bm = __builtin_bit_cast(bf16x8, mid),
-                       bl = __builtin_bit_cast(bf16x8, lo);
+            for (int s = 0; s < 4; ++s) x[4 * gs + s] = fb[st][gs][s][j];
+          bf16x8 bh, bm, bl;
+          split3_bf16(x, bh, bm, bl);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[i], bl, acc[i][j], 0, 0, 0);   // small terms first
