@@ -240,6 +240,11 @@ def main():
                                       "synthetic 84x84x4 u8 frames generated on device",
                                       a.sampler, "hipGraph replay" if not a.no_graph else "eager launches"),
                        "envs_per_gpu": N, "t_max": T, "global_envs": N * world,
+                       "arithmetic": "fp32 results everywhere (parity: logits/values within 1e-4). fp32 MFMA for the "
+                                     "32-row kernels; conv1 and most >64-row contractions run on the bf16 MFMA with each "
+                                     "fp32 operand split EXACTLY into 3 bf16 terms (u8 pixels are exact in one), fp32 "
+                                     "accumulation; of the 9 partial products the 3 below 2^-23 of the leading one are "
+                                     "dropped",
                        "parallelism": "env-sharded dp%d, RCCL sum all-reduce of the flat gradient per update (fc/heads part overlapped with the conv backward)" % world},
             "finite_params": finite,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,

@@ -192,7 +192,7 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
 
 /* Tuning (tools/tune_gemm.py): override the launch configuration of GEMM op `op` (0 conv1_fwd, 1 conv2_fwd,
  * 2 conv3_fwd, 3 fc_fwd, 4 fc_wgrad, 5 fc_dgrad, 6 conv3_wgrad, 7 conv3_dgrad, 8 conv2_wgrad, 9 conv2_dgrad,
- * 10 conv1_wgrad) for batch class 0 (batch <= 64) or 1: cfg = index into the family's configuration table
+ * 10 conv1_wgrad) for batch class 0 (batch <= 64), 1 (batch <= 512) or 2: cfg = index into the family's configuration table
  * (-1 = size heuristic), ksplit = blockIdx.z K split (0 = heuristic), xcd_dim = grid dimension tied to the XCD. */
 int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int ksplit, int xcd_dim);
 

@@ -125,7 +125,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   c->spec = arch_spec(cfg->arch);
   c->max_batch = cfg->max_batch;
   for (int o = 0; o < OP_COUNT; ++o)
-    for (int k = 0; k < 2; ++k) c->tune[o][k] = Tune{-1, 0, -1};
+    for (int k = 0; k < 3; ++k) c->tune[o][k] = Tune{-1, 0, -1};
   default_tuning(c);
   const int64_t B = cfg->max_batch;
   const int A = cfg->num_actions;
@@ -275,7 +275,7 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
 }
 
 int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int ksplit, int xcd_dim) {
-  PAAC_REQUIRE(ctx && op >= 0 && op < OP_COUNT && (batch_class == 0 || batch_class == 1), "paac_debug_set_tuning: bad op/class");
+  PAAC_REQUIRE(ctx && op >= 0 && op < OP_COUNT && batch_class >= 0 && batch_class <= 2, "paac_debug_set_tuning: bad op/class");
   ctx->tune[op][batch_class] = Tune{cfg, ksplit, xcd_dim};
   return 0;
 }

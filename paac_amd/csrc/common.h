@@ -77,11 +77,13 @@ struct Tune {
   int ksplit;  // blockIdx.z K split (slab epilogues), 0 = heuristic
   int xcd;     // grid dimension tied to the XCD (0 M tiles, 1 N tiles, 2 z), -1 none
 };
+inline int batch_class(int batch) { return batch > 512 ? 2 : batch > 64 ? 1 : 0; }
+
 }  // namespace paac
 
 struct paac_ctx {
   paac_cfg cfg;
-  paac::Tune tune[paac::OP_COUNT][2];   // [op][batch class: 0 = batch <= 64, 1 = larger]
+  paac::Tune tune[paac::OP_COUNT][3];   // [op][batch class: 0 = batch <= 64, 1 = batch <= 512, 2 = larger]
   paac::ArchSpec spec;
   paac_layout layout;
   int max_batch;

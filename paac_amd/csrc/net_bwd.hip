@@ -174,7 +174,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
                          int phase, hipStream_t s) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[1];
-  const int cls = batch > 64 ? 1 : 0;
+  const int cls = batch_class(batch);
   const int A = ctx->cfg.num_actions;
   const int i_w1 = 0, i_w2 = 2, i_w3 = 4;
   const int i_wf = (NT::NCONV == 3) ? 6 : 4;
@@ -302,25 +302,24 @@ namespace paac {
 // heuristics.
 void default_tuning(paac_ctx* c) {
   if (c->cfg.arch != PAAC_ARCH_NATURE) return;
-  if (c->max_batch > 2048) return;   // size heuristics (measured better than the 1536-row table at 2688 rows)
-  if (c->max_batch > 512) {
-    // TUNE_N=256 tools/tune_gemm.py (256 envs x t_max 5: 1536-row training forward, 1280-row backward; the 256-row
-    // acting batch shares class 1).  At these sizes the K loops dominate and the split-bf16 path wins for most ops.
-    c->tune[OP_CONV1_FWD][1] = Tune{kExactBf16 + 11, 0, -1};
-    c->tune[OP_CONV2_FWD][1] = Tune{kSplitBf16 + 11, 0, -1};
-    c->tune[OP_CONV3_FWD][1] = Tune{kSplitBf16 + 10, 0, -1};
-    c->tune[OP_FC_FWD][1] = Tune{kSplitBf16 + 4, 4, -1};
-    c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
-    c->tune[OP_FC_DGRAD][1] = Tune{kSplitBf16 + 10, 0, -1};
-    c->tune[OP_CONV3_WGRAD][1] = Tune{kSplitBf16 + 1, 48, 2};
-    c->tune[OP_CONV3_DGRAD][1] = Tune{kSplitBf16 + 10, 0, -1};
-    c->tune[OP_CONV2_WGRAD][1] = Tune{kSplitBf16 + 3, 32, 2};
-    c->tune[OP_CONV2_DGRAD][1] = Tune{10, 0, 0};
-    c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 2, 64, 2};
-    return;
+  if (c->max_batch <= 2048) {
+    // class 2 (more than 512 rows): TUNE_N=256 tools/tune_gemm.py (256 envs x t_max 5: 1536-row training forward,
+    // 1280-row backward).  At these sizes the K loops dominate and the split-bf16 path wins for most ops.  Contexts
+    // sized for more than 2048 rows keep the size heuristics there (measured better at 2688 rows).
+    c->tune[OP_CONV1_FWD][2] = Tune{kExactBf16 + 11, 0, -1};
+    c->tune[OP_CONV2_FWD][2] = Tune{kSplitBf16 + 11, 0, -1};
+    c->tune[OP_CONV3_FWD][2] = Tune{kSplitBf16 + 10, 0, -1};
+    c->tune[OP_FC_FWD][2] = Tune{kSplitBf16 + 4, 4, -1};
+    c->tune[OP_FC_WGRAD][2] = Tune{0, 1, 0};
+    c->tune[OP_FC_DGRAD][2] = Tune{kSplitBf16 + 10, 0, -1};
+    c->tune[OP_CONV3_WGRAD][2] = Tune{kSplitBf16 + 1, 48, 2};
+    c->tune[OP_CONV3_DGRAD][2] = Tune{kSplitBf16 + 10, 0, -1};
+    c->tune[OP_CONV2_WGRAD][2] = Tune{kSplitBf16 + 3, 32, 2};
+    c->tune[OP_CONV2_DGRAD][2] = Tune{10, 0, 0};
+    c->tune[OP_CONV1_WGRAD][2] = Tune{kExactBf16 + 2, 64, 2};
   }
-  // tools/tune_gemm.py on MI355X, 32 envs x t_max 5: acting batch 32 (class 0); training forward over 192 rows and
-  // backward over 160 (class 1)
+  // classes 0 and 1: tools/tune_gemm.py on MI355X, 32 envs x t_max 5: acting batch 32 (class 0); training forward over
+  // 192 rows and backward over 160 (class 1)
   c->tune[OP_CONV1_FWD][0] = Tune{kExactBf16 + 4, 0, -1};
   c->tune[OP_CONV1_FWD][1] = Tune{kExactBf16 + 10, 0, -1};
   c->tune[OP_CONV2_FWD][1] = Tune{kSplitBf16 + 12, 0, -1};

@@ -76,7 +76,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[wsi];
   ctx->last_ws = wsi;
-  const int cls = batch > 64 ? 1 : 0;
+  const int cls = batch_class(batch);
   const int A = ctx->cfg.num_actions;
   int t = 0;
   const float* w1 = params + L.offset[t++];

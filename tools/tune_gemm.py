@@ -87,9 +87,14 @@ def candidates(op, cls):
 
 
 best = {}
-for cls, fn, label in ((0, fwd_act, "act B=%d" % N), (1, train, "train B=%d" % (N * T))):
-    if cls == 1 and N * T <= 64:
-        continue
+def batch_class(b):
+    return 2 if b > 512 else (1 if b > 64 else 0)
+
+
+# the library picks the table row by batch: acting batch N, training batches N*(T+1) / N*T (same class here)
+for cls, fn, label in ((batch_class(N), fwd_act, "act B=%d" % N), (batch_class(N * T), train, "train B=%d" % (N * T))):
+    if fn is train and batch_class(N * T) == batch_class(N):
+        print("(acting and training batch share class %d: tuning the training step only would override it)" % cls)
     base = time_graph(fn)
     print("%s: heuristic graph %.1f us" % (label, base), flush=True)
     ops = [o for o in OPS_ACTIVE if (o <= 3 or cls == 1)]
