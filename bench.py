@@ -128,13 +128,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        ro.run_cycle()
+    ro.run_cycles(a.warmup)
     ro.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ro.run_cycle()
+    ro.run_cycles(a.steps)          # exactly K cycles (graph replay batches them 4 per launch where it can)
     ro.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

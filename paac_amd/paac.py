@@ -12,6 +12,7 @@ train() has two executions of the SAME cycle (paac.py:99-183):
     the reference's numpy sampler on the same np.random seed (paac_sample_mt).
 """
 import logging
+import os
 import time
 
 import numpy as np
@@ -68,6 +69,7 @@ class DeviceRollout(object):
         self.graph_a = [None, None]
         self.graph_conv = [None, None]
         self.graph_b = None
+        self.graph_multi = None                        # MULTI consecutive cycles (parity 0 first) in one launch
         self.phased = L._world() > 1
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
@@ -158,6 +160,26 @@ class DeviceRollout(object):
                     self.graph_conv[parity] = captured(lambda: self._backward_conv(parity))
             if world > 1:
                 self.graph_b = captured(self._update)
+            else:
+                self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
+
+    # cycles per launch of graph_multi (even: the ring parity is back at 0 afterwards)
+    MULTI = max(2, int(os.environ.get("PAAC_CYCLES_PER_LAUNCH", "4")) // 2 * 2)
+
+    def run_cycles(self, count):
+        """`count` cycles.  Single-process graph replay batches them MULTI per hipGraph launch where it can: the gap
+        between two graph launches on the GPU (about 8 us) is paid once per MULTI cycles instead of every cycle."""
+        count = int(count)
+        while count > 0:
+            if self.use_graph and not self.phased and self.parity == 0 and count >= self.MULTI:
+                with torch.cuda.stream(self.stream):
+                    if self.graph_a[0] is None:
+                        self.capture()
+                    self.graph_multi.launch()
+                count -= self.MULTI
+            else:
+                self.run_cycle()
+                count -= 1
 
     def run_cycle(self):
         with torch.cuda.stream(self.stream):
@@ -200,12 +222,13 @@ class DeviceRollout(object):
         return count, [(float(rewards[i]), int(lens[i])) for i in idx]
 
     def close(self):
-        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b):
+        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b, self.graph_multi):
             if g is not None:
                 g.close()
         self.graph_a = [None, None]
         self.graph_conv = [None, None]
         self.graph_b = None
+        self.graph_multi = None
 
 
 class DeviceObservations(object):

@@ -167,3 +167,33 @@ def test_cpu_device_is_rejected():
     args = make_args(device="/cpu:0", emulator_counts=2)
     with pytest.raises(RuntimeError):
         build_learner(args)
+
+
+def test_batched_graph_launches_equal_single_cycles():
+    """DeviceRollout.run_cycles(n) replays 4 cycles per hipGraph launch where it can: same trajectory, same weights,
+    same counters as n single-cycle launches."""
+    from paac_amd.paac import DeviceRollout
+    N, T, cycles = 8, 5, 11
+    outs = []
+    for batched in (False, True):
+        args = make_args(game="breakout", arch="NATURE", emulator_counts=N, emulator_workers=0, max_local_steps=T,
+                         max_global_steps=1 << 40, synthetic_terminal_p=0.1)
+        learner, _, _ = build_learner(args)
+        np.random.seed(5)
+        learner.global_step = learner.init_network()
+        ro = DeviceRollout(learner, learner.environment_creator.device_env_spec, sampler="numpy", use_graph=True)
+        if batched:
+            ro.run_cycles(1)            # parity 1: the next call must fall back to a single cycle first
+            ro.run_cycles(cycles - 1)   # 1 single + 2 x 4 batched + 1 single
+        else:
+            for _ in range(cycles):
+                ro.run_cycle()
+        ro.synchronize()
+        outs.append((learner.network.get_parameters(), ro.actions.cpu().numpy().copy(), int(ro.global_step_dev.item()),
+                     float(learner.lr_dev.item()), ro.rollout_states().cpu().numpy().copy()))
+        ro.close()
+    (p0, a0, g0, lr0, s0), (p1, a1, g1, lr1, s1) = outs
+    assert g0 == g1 == cycles * N * T and lr0 == lr1
+    assert np.array_equal(a0, a1) and np.array_equal(s0, s1)
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
