@@ -340,24 +340,33 @@ class PAACLearner(ActorLearner):
         steps_per_cycle = N * T * world
         metrics = self._open_metrics()
         episodes_seen = 0
+        from .actor_learner import CHECKPOINT_INTERVAL
         while self.global_step < self.max_global_steps:
             loop_start_time = time.time()
-            self.rollout.run_cycle()
-            self.global_step += steps_per_cycle
-            counter += 1
+            # as many cycles per call as fit before the next event the reference checks every cycle: the end of
+            # training, the progress line (paac.py:172) and the checkpoint (actor_learner.py:89-93)
+            chunk = 1
+            if float(log_every).is_integer():
+                until_end = -(-(self.max_global_steps - self.global_step) // steps_per_cycle)
+                until_log = int(log_every) - counter % int(log_every)
+                until_save = -(-(self.last_saving_step + CHECKPOINT_INTERVAL - self.global_step) // steps_per_cycle)
+                chunk = max(1, min(until_end, until_log, until_save))
+            self.rollout.run_cycles(chunk)
+            self.global_step += chunk * steps_per_cycle
+            counter += chunk
             if counter % log_every == 0:
                 self.rollout.synchronize()
                 curr_time = time.time()
                 count, eps = self.rollout.finished_episodes()
                 last_ten = 0.0 if len(eps) < 1 else np.mean([r for r, _ in eps[-10:]])
                 logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), last 10 rewards avg {}"
-                             .format(self.global_step, steps_per_cycle / (curr_time - loop_start_time),
+                             .format(self.global_step, chunk * steps_per_cycle / (curr_time - loop_start_time),
                                      (self.global_step - global_step_start) / (curr_time - start_time), last_ten))
                 if metrics is not None:
                     for r, l in eps[max(0, len(eps) - (count - episodes_seen)):]:     # new since the last drain
                         metrics.write("episode", global_step=int(self.global_step), reward=float(r), length=int(l))
                     episodes_seen = count
-                    self._progress_record(steps_per_cycle / (curr_time - loop_start_time),
+                    self._progress_record(chunk * steps_per_cycle / (curr_time - loop_start_time),
                                           (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
             self.save_vars()
         self.rollout.synchronize()
