@@ -70,6 +70,8 @@ class DeviceRollout(object):
         self.graph_conv = [None, None]
         self.graph_b = None
         self.graph_multi = None                        # MULTI consecutive cycles (parity 0 first) in one launch
+        self.graph_ua = [None, None]                   # data parallel: update of the previous cycle + graph_a
+        self.pending_update = False
         self.phased = L._world() > 1
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
@@ -158,6 +160,9 @@ class DeviceRollout(object):
                 self.graph_a[parity] = captured(lambda: cycle(parity, world == 1))
                 if world > 1:
                     self.graph_conv[parity] = captured(lambda: self._backward_conv(parity))
+                    # the optimizer step of cycle k rides in front of cycle k+1's graph: two graph launches per
+                    # cycle around the exchange instead of three (synchronize() flushes a pending step)
+                    self.graph_ua[parity] = captured(lambda: (self._update(), cycle(parity, False)))
             if world > 1:
                 self.graph_b = captured(self._update)
             else:
@@ -186,10 +191,12 @@ class DeviceRollout(object):
             if self.use_graph:
                 if self.graph_a[0] is None:
                     self.capture()
-                self.graph_a[self.parity].launch()
                 if self.phased:
+                    (self.graph_ua if self.pending_update else self.graph_a)[self.parity].launch()
                     self._exchange(self.graph_conv[self.parity].launch)
-                    self.graph_b.launch()
+                    self.pending_update = True
+                else:
+                    self.graph_a[self.parity].launch()
             else:
                 self._rollout_and_backward(self.parity)
                 if self.phased:
@@ -209,6 +216,12 @@ class DeviceRollout(object):
                 work.wait()
 
     def synchronize(self):
+        """Completes everything issued so far, including a data-parallel optimizer step still waiting to ride in
+        front of the next cycle: afterwards weights, optimizer state and buffers are those of the last cycle."""
+        if self.pending_update:
+            with torch.cuda.stream(self.stream):
+                self.graph_b.launch()
+            self.pending_update = False
         self.stream.synchronize()
 
     def finished_episodes(self):
@@ -222,13 +235,15 @@ class DeviceRollout(object):
         return count, [(float(rewards[i]), int(lens[i])) for i in idx]
 
     def close(self):
-        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b, self.graph_multi):
+        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b, self.graph_multi,
+                  self.graph_ua[0], self.graph_ua[1]):
             if g is not None:
                 g.close()
         self.graph_a = [None, None]
         self.graph_conv = [None, None]
         self.graph_b = None
         self.graph_multi = None
+        self.graph_ua = [None, None]
 
 
 class DeviceObservations(object):
@@ -368,6 +383,8 @@ class PAACLearner(ActorLearner):
                     episodes_seen = count
                     self._progress_record(chunk * steps_per_cycle / (curr_time - loop_start_time),
                                           (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
+            if self.global_step - self.last_saving_step >= CHECKPOINT_INTERVAL:
+                self.rollout.synchronize()           # the checkpoint must see the finished update, nothing in flight
             self.save_vars()
         self.rollout.synchronize()
 

@@ -43,10 +43,12 @@ def _run(rank, world, port, out_dir, n_per_rank, cycles):
     L.network.set_parameters(onet.init_params("NATURE", args.num_actions, np.random.RandomState(0), dtype=np.float32))
     ro = DeviceRollout(L, ec.device_env_spec, sampler="philox", sampler_seed=9, env_offset=rank * n_per_rank, use_graph=True)
     acts = []
-    for _ in range(cycles):
-        ro.run_cycle()
-        ro.synchronize()
-        acts.append(ro.actions.cpu().numpy().copy())
+    ro.run_cycle()
+    ro.synchronize()
+    acts.append(ro.actions.cpu().numpy().copy())
+    ro.run_cycles(cycles - 1)       # back to back: with two ranks the optimizer step rides in front of the next cycle
+    ro.synchronize()
+    acts.append(ro.actions.cpu().numpy().copy())
     p = L.network.get_parameters()
     np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), actions=np.stack(acts),
              gstep=int(ro.global_step_dev.item()), lr=float(L.lr_dev.item()), **p)
@@ -58,7 +60,7 @@ def _run(rank, world, port, out_dir, n_per_rank, cycles):
 
 def test_two_ranks_track_single_process(tmp_path):
     import torch.multiprocessing as mp
-    N, cycles = 4, 3
+    N, cycles = 4, 5
     mp.spawn(_run, args=(2, _free_port(), str(tmp_path), N, cycles), nprocs=2, join=True)
     mp.spawn(_run, args=(1, 0, str(tmp_path), 2 * N, cycles), nprocs=1, join=True)
     r0 = np.load(tmp_path / "w2_r0.npz")
