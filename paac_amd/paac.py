@@ -73,6 +73,7 @@ class DeviceRollout(object):
         self.graph_ua = [None, None]                   # data parallel: update of the previous cycle + graph_a
         self.pending_update = False
         self.phased = L._world() > 1
+        self.side_group = parallel.side_group() if self.phased else None    # collective: all ranks construct a rollout
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
@@ -210,7 +211,8 @@ class DeviceRollout(object):
         grad = self.L.grad
         tail = parallel.allreduce_sum_async(grad[self.tail_offset:])
         conv_backward()
-        head = parallel.allreduce_sum_async(grad[:self.tail_offset])
+        # the small conv part goes out on a second communicator: it does not wait for the 6.4 MB one to finish
+        head = parallel.allreduce_sum_async(grad[:self.tail_offset], group=self.side_group)
         for work in (tail, head):
             if work is not None:
                 work.wait()

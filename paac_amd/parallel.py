@@ -35,12 +35,25 @@ def allreduce_sum_(flat_grad):
     return flat_grad
 
 
-def allreduce_sum_async(flat_grad):
+_side_group = None
+
+
+def side_group():
+    """A second process group over the same ranks (collective call: every rank must make it at the same point).
+    Its collectives have their own communicator and stream, so a small all-reduce issued on it does not queue behind a
+    large one still in flight on the default group."""
+    global _side_group
+    if _side_group is None and world_size() > 1:
+        _side_group = dist.new_group(ranks=list(range(world_size())))
+    return _side_group
+
+
+def allreduce_sum_async(flat_grad, group=None):
     """Start an in-place sum all-reduce; returns the work handle (None for a single process).  With RCCL the
     collective runs on the process group's stream after the work already queued on the current stream, and
     `work.wait()` makes the current stream wait for it -- no host synchronisation."""
     if world_size() > 1:
-        return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+        return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 
 
