@@ -46,6 +46,44 @@ __global__ void k_persistent(float* a, float* b, int nb, int phases, unsigned* c
   }
 }
 
+// Variant without fences: the phase data bypasses the (non-coherent) XCD L2s -- device-scope relaxed atomic stores
+// and loads, one dword each -- so the barrier is only the counter: one atomic add + polling.
+__device__ __forceinline__ bool grid_barrier_nofence(unsigned* ctr, unsigned target, unsigned* err) {
+  __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have left (vmcnt 0)
+  __syncthreads();
+  __shared__ int ok2;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int good = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!good) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok2 = good;
+  }
+  __syncthreads();
+  return ok2 != 0;
+}
+
+__global__ void k_persistent_nofence(float* a, float* b, int nb, int phases, unsigned* ctr, unsigned* err, unsigned base) {
+  for (int ph = 0; ph < phases; ++ph) {
+    const float* src = (ph & 1) ? b : a;
+    float* dst = (ph & 1) ? a : b;
+    const int peer = (blockIdx.x * 37 + 11) % nb;
+    for (int i = threadIdx.x; i < SLICE; i += blockDim.x) {
+      const float v = __hip_atomic_load(src + peer * SLICE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + blockIdx.x * SLICE + i, v + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!grid_barrier_nofence(ctr, base + (unsigned)(ph + 1) * nb, err)) return;
+  }
+}
+
+__global__ void k_barrier_only_nofence(int nb, int phases, unsigned* ctr, unsigned* err, unsigned base) {
+  for (int ph = 0; ph < phases; ++ph)
+    if (!grid_barrier_nofence(ctr, base + (unsigned)(ph + 1) * nb, err)) return;
+}
+
 // barrier only (no data): the pure synchronisation cost
 __global__ void k_barrier_only(int nb, int phases, unsigned* ctr, unsigned* err, unsigned base) {
   for (int ph = 0; ph < phases; ++ph)
@@ -83,6 +121,11 @@ int main() {
         else hipLaunchKernelGGL(k_barrier_only, dim3(nb), dim3(threads), 0, s, nb, PH, ctr, err, base);
         base += (unsigned)PH * nb;
       };
+      auto run_nf = [&](bool data) {
+        if (data) hipLaunchKernelGGL(k_persistent_nofence, dim3(nb), dim3(threads), 0, s, a, b, nb, PH, ctr, err, base);
+        else hipLaunchKernelGGL(k_barrier_only_nofence, dim3(nb), dim3(threads), 0, s, nb, PH, ctr, err, base);
+        base += (unsigned)PH * nb;
+      };
       run(true);
       CK(hipStreamSynchronize(s));
       std::vector<float> h(nb * SLICE);
@@ -98,6 +141,23 @@ int main() {
       for (int r = 0; r < REP; ++r) run(false);
       CK(hipStreamSynchronize(s));
       const double t_bar = (now() - t0) / (REP * PH);
+      // fence-free variant
+      CK(hipMemset(a, 0, nb * SLICE * 4)); CK(hipMemset(b, 0, nb * SLICE * 4));
+      run_nf(true);
+      CK(hipStreamSynchronize(s));
+      CK(hipMemcpy(h.data(), a, nb * SLICE * 4, hipMemcpyDeviceToHost));
+      int bad_nf = 0;
+      for (float v : h) bad_nf += (v != (float)PH);
+      t0 = now();
+      for (int r = 0; r < REP; ++r) run_nf(true);
+      CK(hipStreamSynchronize(s));
+      const double t_pers_nf = (now() - t0) / (REP * PH);
+      t0 = now();
+      for (int r = 0; r < REP; ++r) run_nf(false);
+      CK(hipStreamSynchronize(s));
+      const double t_bar_nf = (now() - t0) / (REP * PH);
+      printf("   fence-free (device-scope atomic loads/stores for the data): %.2f us/phase (barrier alone %.2f), wrong %d\n",
+             t_pers_nf, t_bar_nf, bad_nf);
       CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
       printf("workgroups %4d x %3d threads: graph kernel boundary %.2f us/phase | persistent + grid barrier %.2f us/phase "
              "(barrier alone %.2f) | wrong %d, timeout flag %u\n", nb, threads, t_graph, t_pers, t_bar, bad, herr);
