@@ -195,6 +195,7 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
  * 10 conv1_wgrad) for batch class 0 (batch <= 64), 1 (batch <= 512) or 2: cfg = index into the family's configuration table
  * (-1 = size heuristic), ksplit = blockIdx.z K split (0 = heuristic), xcd_dim = grid dimension tied to the XCD. */
 int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int ksplit, int xcd_dim);
+int paac_debug_get_tuning(paac_ctx* ctx, int op, int batch_class, int* cfg, int* ksplit, int* xcd_dim);
 
 /* Diagnostic: writes {s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks} to out2_dev[0..1]. */
 int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "paac_graph_destroy": (c_int, [c_void_p]),
     "paac_debug_activation": (c_int64, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "paac_debug_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "paac_debug_get_tuning": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "paac_debug_clock": (c_int, [c_void_p, c_void_p]),
     "paac_prof_enable": (c_int, [c_void_p, c_int]),
     "paac_prof_read": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_int]),

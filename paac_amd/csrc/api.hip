@@ -280,6 +280,16 @@ int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int k
   return 0;
 }
 
+int paac_debug_get_tuning(paac_ctx* ctx, int op, int batch_class, int* cfg, int* ksplit, int* xcd_dim) {
+  PAAC_REQUIRE(ctx && op >= 0 && op < OP_COUNT && batch_class >= 0 && batch_class <= 2 && cfg && ksplit && xcd_dim,
+               "paac_debug_get_tuning: bad argument");
+  const Tune t = ctx->tune[op][batch_class];
+  *cfg = t.cfg;
+  *ksplit = t.ksplit;
+  *xcd_dim = t.xcd;
+  return 0;
+}
+
 // ---- hipGraph helpers -------------------------------------------------------------------------
 int paac_graph_begin(paac_stream_t stream) {
   PAAC_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));

@@ -328,9 +328,9 @@ void default_tuning(paac_ctx* c) {
   c->tune[OP_FC_FWD][0] = Tune{0, 8, 2};
   c->tune[OP_FC_FWD][1] = Tune{kSplitBf16 + 1, 8, 2};
   c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
-  c->tune[OP_FC_DGRAD][1] = Tune{kSplitBf16 + 5, 0, -1};
+  c->tune[OP_FC_DGRAD][1] = Tune{kSplitBf16 + 1, 0, -1};
   c->tune[OP_CONV3_WGRAD][1] = Tune{kSplitBf16 + 1, 48, 2};
-  c->tune[OP_CONV3_DGRAD][1] = Tune{11, 0, -1};
+  c->tune[OP_CONV3_DGRAD][1] = Tune{kSplitBf16 + 11, 0, -1};
   c->tune[OP_CONV2_WGRAD][1] = Tune{0, 32, 2};
   c->tune[OP_CONV2_DGRAD][1] = Tune{9, 0, -1};
   c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 2, 64, 2};

@@ -33,6 +33,16 @@ def set_tune(op, cls, cfg, ks, xcd):
     _lib.check(lib.paac_debug_set_tuning(ctx.handle, op, cls, cfg, ks, xcd), "set_tuning")
 
 
+REPS = int(os.environ.get("TUNE_REPS", "25"))
+MARGIN = float(os.environ.get("TUNE_MARGIN", "0.3"))   # us a candidate must win by
+
+
+def get_tune(op, cls):
+    c, k, x = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.paac_debug_get_tuning(ctx.handle, op, cls, ctypes.byref(c), ctypes.byref(k), ctypes.byref(x)), "get_tuning")
+    return (c.value, k.value, x.value)
+
+
 def time_graph(fn, reps=40):
     with torch.cuda.stream(stream):
         g = hip_ops.Graph(); g.begin(); fn(); g.end()
@@ -87,6 +97,7 @@ def candidates(op, cls):
 
 
 best = {}
+start = {(op, cls): get_tune(op, cls) for op in range(11) for cls in range(3)}
 def batch_class(b):
     return 2 if b > 512 else (1 if b > 64 else 0)
 
@@ -96,20 +107,20 @@ for cls, fn, label in ((batch_class(N), fwd_act, "act B=%d" % N), (batch_class(N
     if fn is train and batch_class(N * T) == batch_class(N):
         print("(acting and training batch share class %d: tuning the training step only would override it)" % cls)
     base = time_graph(fn)
-    print("%s: heuristic graph %.1f us" % (label, base), flush=True)
+    print("%s: graph with the library's table %.1f us" % (label, base), flush=True)
     ops = [o for o in OPS_ACTIVE if (o <= 3 or cls == 1)]
     for rnd in range(2):
         for op in ops:
-            cur = best.get((op, cls), (-1, 0, -1))
+            cur = best.get((op, cls), start[(op, cls)])      # start from the library's own table
             results = []
             for cand in candidates(op, cls):
                 set_tune(op, cls, *cand)
-                results.append((time_graph(fn, reps=25), cand))
+                results.append((time_graph(fn, reps=REPS), cand))
             set_tune(op, cls, *cur)
-            ref = time_graph(fn, reps=25)
+            ref = time_graph(fn, reps=REPS)
             results.sort()
             t_best, c_best = results[0]
-            if t_best < ref - 0.3:
+            if t_best < ref - MARGIN:
                 best[(op, cls)] = c_best
                 set_tune(op, cls, *c_best)
             print("  round %d %-12s current %s %.1f us | best %s %.1f us | top3 %s" % (
