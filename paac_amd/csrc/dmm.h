@@ -206,6 +206,12 @@ struct Dmm {
   static constexpr int GS = XB ? 2 : 1;          // 16-wide K groups per pipeline stage
   static constexpr int KSTAGE = 16 * GS;
   static_assert(XB != 1 || (U8 && BP == FRAG_MN), "exact-bf16 path: u8 A operand, fp32 FRAG_MN B operand");
+  // conv1 forward on the exact path: a K stage is exactly one patch row (8 pixels x 4 channels = 32 contiguous
+  // bytes), so lane slot kq takes the instruction's natural k = 8 kq .. 8 kq + 7 = two adjacent pixels: ONE 8-byte
+  // load per tile and stage.  Its weights are always in range (N is a multiple of 32, K of 32): plain 8-byte
+  // loads for them too -- half the load instructions of the checked dword pairs.
+  static constexpr bool NAT = (XB == 1) && (AP == FRAG_K) && !BIASROW && (TN == 2) && (G_::KW * G_::C == 32) &&
+                              !((G_::PH != 0) || (G_::PW != 0));
   static_assert(XB != 2 || !U8, "split path: fp32 operands");
   static constexpr int THREADS = 64 * NWM * NWN * WK;
   static constexpr int M_TILE = NWM * TM * 16, N_TILE = NWN * TN * 16, WAVES_K = WK;
@@ -294,8 +300,8 @@ struct Dmm {
       const int ox = rem - oy * G::OW;
       a_iy0[t] = oy * G::S - G::PH;
       a_ix0[t] = ox * G::S - G::PW;
-      const int base = ((b * G::IH + a_iy0[t]) * G::IW + a_ix0[t]) * G::C + 4 * kq;   // elements; may be < 0 when padded
-      a_voff[t] = ok ? (unsigned)base * ES : kOob;
+      const int base = ((b * G::IH + a_iy0[t]) * G::IW + a_ix0[t]) * G::C + (NAT ? 8 : 4) * kq;   // elements; may be < 0 when padded
+      a_voff[t] = ok ? (unsigned)base * ES : (NAT ? 0u : kOob);   // NAT: plain loads -- an out-of-range row reads row 0, its result is never stored
       if constexpr (G::PADDED) a_iy0[t] = ok ? a_iy0[t] : -(1 << 20);   // padded path re-derives validity per group
     }
   } else {
@@ -317,7 +323,8 @@ struct Dmm {
     // FRAG_MN B: row 4*kq + s of the group, TN consecutive columns
     const bool ok = n0 + TN * li < p.N;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b_voff[s] = ok ? (unsigned)((4 * kq + s) * p.ldb + n0 + TN * li) * 4u : kOob;
+    for (int s = 0; s < 4; ++s)
+      b_voff[s] = ok ? (unsigned)(((NAT ? 8 : 4) * kq + s) * p.ldb + n0 + TN * li) * 4u : (NAT ? 0u : kOob);
   }
 
   // ---- K range of this wave -------------------------------------------------------------------------
@@ -347,8 +354,17 @@ struct Dmm {
       if constexpr (!G::PADDED) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-          if constexpr (XB == 1) ua[slot][gs][t] = __builtin_amdgcn_raw_buffer_load_b32(rsA, a_voff[t] | kill, goff, 0);
-          else fa[slot][gs][t] = bload4<U8>(rsA, a_voff[t] | kill, goff);
+          if constexpr (NAT) {
+            if (gs == 0) {   // both dwords of the stage at once (the stage is one patch row: goff of gs 0)
+              const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.A) + a_voff[t] + goff);
+              ua[slot][0][t] = w.x;
+              ua[slot][1][t] = w.y;
+            }
+          } else if constexpr (XB == 1) {
+            ua[slot][gs][t] = __builtin_amdgcn_raw_buffer_load_b32(rsA, a_voff[t] | kill, goff, 0);
+          } else {
+            fa[slot][gs][t] = bload4<U8>(rsA, a_voff[t] | kill, goff);
+          }
         }
       } else {
         const int kw = kwc / G::C;
@@ -396,9 +412,19 @@ struct Dmm {
     } else {
       // the whole offset goes through the range-checked VGPR offset: rows >= K (the tail of a K that is not a
       // multiple of 16) and dead groups read as zero
-      const unsigned goff = live ? (unsigned)(k16 * p.ldb) * 4u : kOob;
+      if constexpr (NAT) {
+        // rows 32 g + 8 kq + 4 gs + s; a dead stage re-reads stage 0 (valid memory, never consumed)
+        const unsigned goff = live ? (unsigned)((g * 32 + 4 * gs) * p.ldb) * 4u : 0u;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) fb[slot][gs][s] = bloadv<TN>(rsB, b_voff[s] + goff, 0);
+        for (int s = 0; s < 4; ++s) {
+          const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.B) + b_voff[s] + goff);
+          fb[slot][gs][s] = (f32x4){t.x, t.y, 0.f, 0.f};
+        }
+      } else {
+        const unsigned goff = live ? (unsigned)(k16 * p.ldb) * 4u : kOob;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fb[slot][gs][s] = bloadv<TN>(rsB, b_voff[s] + goff, 0);
+      }
     }
     }   // gs
   };
