@@ -212,6 +212,9 @@ struct Dmm {
   // loads for them too -- half the load instructions of the checked dword pairs.
   static constexpr bool NAT = (XB == 1) && (AP == FRAG_K) && !BIASROW && (TN == 2) && (G_::KW * G_::C == 32) &&
                               !((G_::PH != 0) || (G_::PW != 0));
+  // A FRAG_MN B operand of width 2 without a bias row is always a weight matrix [K, N] with N a multiple of 32 and K of
+  // 16 (conv1, NIPS conv2, the half-width forward tiles): no range check needed, plain 8-byte loads.
+  static constexpr bool B_PLAIN = (BP == FRAG_MN) && !BIASROW && (TN == 2) && !NAT;
   static_assert(XB != 2 || !U8, "split path: fp32 operands");
   static constexpr int THREADS = 64 * NWM * NWN * WK;
   static constexpr int M_TILE = NWM * TM * 16, N_TILE = NWN * TN * 16, WAVES_K = WK;
@@ -324,7 +327,7 @@ struct Dmm {
     const bool ok = n0 + TN * li < p.N;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      b_voff[s] = ok ? (unsigned)(((NAT ? 8 : 4) * kq + s) * p.ldb + n0 + TN * li) * 4u : (NAT ? 0u : kOob);
+      b_voff[s] = ok ? (unsigned)(((NAT ? 8 : 4) * kq + s) * p.ldb + n0 + TN * li) * 4u : ((NAT || B_PLAIN) ? 0u : kOob);
   }
 
   // ---- K range of this wave -------------------------------------------------------------------------
@@ -415,6 +418,13 @@ struct Dmm {
       if constexpr (NAT) {
         // rows 32 g + 8 kq + 4 gs + s; a dead stage re-reads stage 0 (valid memory, never consumed)
         const unsigned goff = live ? (unsigned)((g * 32 + 4 * gs) * p.ldb) * 4u : 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.B) + b_voff[s] + goff);
+          fb[slot][gs][s] = (f32x4){t.x, t.y, 0.f, 0.f};
+        }
+      } else if constexpr (B_PLAIN) {
+        const unsigned goff = live ? (unsigned)(k16 * p.ldb) * 4u : 0u;   // a dead group re-reads group 0: never consumed
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.B) + b_voff[s] + goff);

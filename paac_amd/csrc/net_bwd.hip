@@ -323,7 +323,7 @@ void default_tuning(paac_ctx* c) {
   c->tune[OP_CONV1_FWD][0] = Tune{kExactBf16 + 4, 0, -1};
   c->tune[OP_CONV1_FWD][1] = Tune{kExactBf16 + 10, 0, -1};
   c->tune[OP_CONV2_FWD][1] = Tune{kSplitBf16 + 12, 0, -1};
-  c->tune[OP_CONV3_FWD][0] = Tune{1, 0, -1};
+  c->tune[OP_CONV3_FWD][0] = Tune{kNarrow + 1, 0, -1};
   c->tune[OP_CONV3_FWD][1] = Tune{kSplitBf16 + 12, 0, -1};
   c->tune[OP_FC_FWD][0] = Tune{0, 8, 2};
   c->tune[OP_FC_FWD][1] = Tune{kSplitBf16 + 1, 8, 2};

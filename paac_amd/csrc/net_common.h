@@ -91,6 +91,8 @@ static int pick_ksplit(long tiles, int wk, int ngroups, int max_split, int targe
 #define PAAC_WGRAD_SPLIT_CFGS(X) X(0, 4, 4, 2) X(1, 4, 2, 2) X(3, 4, 4, 3)
 constexpr int kFwdCfgs = 13, kDgradCfgs = 12, kWgradCfgs = 9;
 constexpr int kExactBf16 = 100;   // cfg ids from here on: the same table entry on the exact-bf16 path (u8 operand only)
+constexpr int kNarrow = 300;       // ... with half-width N tiles (32 columns per wave): more workgroups for the small acting batch
+#define PAAC_FWD_NARROW_CFGS(X) X(0, 1, 1, 8, 5) X(1, 1, 1, 4, 5) X(2, 2, 1, 8, 3) X(3, 2, 1, 4, 3) X(6, 1, 2, 4, 4)
 constexpr int kSplitBf16 = 200;   // ... on the six-product split-bf16 path (fp32 operands; dmm.h: XB = 2)
 constexpr int split_pf(int pf) { return pf > 2 ? 2 : pf; }   // a stage is two K groups there: shallower ring
 

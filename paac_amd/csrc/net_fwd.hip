@@ -48,6 +48,18 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
       return ksplit;
     }
   }
+  if constexpr (!U8 && VN == 4 && EPI == EPI_BIAS_RELU) {
+    if (cfg >= kNarrow) {
+      switch (cfg - kNarrow) {
+#define X(id, TM, NWM, WK, PF) \
+  case id: launch_dmm<Dmm<G, U8, FRAG_K, FRAG_MN, TM, 2, NWM, 1, WK, 1, EPI, false, PF>>(g, ksplit, ksplit, xcd, s); return ksplit;
+        PAAC_FWD_NARROW_CFGS(X)
+#undef X
+        default: cfg -= kNarrow; break;
+      }
+    }
+  }
+  if (cfg >= kNarrow) cfg -= kNarrow;
   if constexpr (!U8) {
     if (cfg >= kSplitBf16) {
       switch (cfg - kSplitBf16) {

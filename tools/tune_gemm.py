@@ -78,6 +78,7 @@ def candidates(op, cls):
             out += [(100 + c, 0, -1) for c in range(13)]      # conv1 on the exact-bf16 path
         else:
             out += [(200 + c, 0, -1) for c in range(13)]      # six-product split-bf16 path
+            out += [(300 + c, 0, -1) for c in (0, 1, 2, 3, 6)]  # half-width N tiles
     elif op == 3:
         for c in list(range(13)) + [200 + c for c in range(13)]:
             for ks in (1, 2, 4, 8):
