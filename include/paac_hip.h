@@ -80,6 +80,16 @@ int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* state
                         float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
                         uint32_t env_offset, int32_t* actions, paac_stream_t stream);
 
+/* paac_forward_sample with the step of the device-resident synthetic environments (paac_synth_step, path A) inside
+ * the heads launch: row i's workgroup samples action i and does environment i's bookkeeping, extra workgroups shift
+ * the observation stacks `states` -> `stack_out`.  One launch less per rollout step; same results as
+ * paac_forward_sample followed by paac_synth_step(env_seed, ...). */
+int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                                   float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
+                                   uint32_t env_offset, int32_t* actions, uint64_t env_seed, uint32_t terminal_threshold,
+                                   uint8_t* stack_out, float* rewards_out, float* masks_out, float* ep_reward,
+                                   int32_t* ep_len, void* finished, paac_stream_t stream);
+
 /* Training forward alone (into the ctx's TRAINING activation set, separate from the one paac_forward* use).
  * Follow with paac_loss_backward(forward_done=1) on the same states with the same OR A SMALLER batch: activations
  * are row-major per sample, so a caller may append the bootstrap observations (paac.py:140-142) as extra rows,

@@ -67,6 +67,9 @@ _SIGNATURES = {
     "paac_sample_mt_synth_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_uint32, c_int, c_uint32, c_void_p,
                                           c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p]),
+    "paac_forward_sample_synth_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_void_p,
+                                               c_uint64, c_uint32, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "paac_graph_begin": (c_int, [c_void_p]),
     "paac_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "paac_graph_launch": (c_int, [c_void_p, c_void_p]),

@@ -221,7 +221,25 @@ int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* state
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_forward_sample: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
   const int rc = launch_forward_sample(ctx, params, states, batch, probs, values, seed, step_base_dev, step_offset,
-                                       env_offset, actions, (hipStream_t)stream);
+                                       env_offset, actions, nullptr, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                                   float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
+                                   uint32_t env_offset, int32_t* actions, uint64_t env_seed, uint32_t terminal_threshold,
+                                   uint8_t* stack_out, float* rewards_out, float* masks_out, float* ep_reward,
+                                   int32_t* ep_len, void* finished, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states && actions && stack_out && rewards_out && masks_out && ep_reward && ep_len,
+               "paac_forward_sample_synth_step: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_forward_sample_synth_step: batch %d outside (0, max_batch=%d]",
+               batch, ctx->max_batch);
+  PAAC_REQUIRE(states != stack_out, "paac_forward_sample_synth_step: the step cannot shift the stacks in place");
+  const int rc = launch_forward_sample_step(ctx, params, states, batch, probs, values, seed, step_base_dev, step_offset,
+                                            env_offset, actions, env_seed, terminal_threshold, stack_out, rewards_out,
+                                            masks_out, ep_reward, ep_len, finished, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;

@@ -148,9 +148,15 @@ inline void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, int part, A
 // launchers implemented in the kernel translation units
 int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,
                    float* probs, float* values, hipStream_t s);
+struct SynthStepArgs;
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
                           float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
-                          uint32_t env_offset, int32_t* actions, hipStream_t s);
+                          uint32_t env_offset, int32_t* actions, const SynthStepArgs* step, hipStream_t s);
+int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                               float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
+                               uint32_t env_offset, int32_t* actions, uint64_t env_seed, uint32_t thresh,
+                               uint8_t* stack_out, float* rewards, float* masks, float* ep_reward, int32_t* ep_len,
+                               void* finished, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s);
 

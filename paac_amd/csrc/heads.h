@@ -5,6 +5,7 @@
 // in registers, and block-wide sums go through LDS in two short stages instead of long ds_bpermute chains.
 #pragma once
 #include "common.h"
+#include "synth_dev.h"
 
 namespace paac {
 
@@ -63,6 +64,21 @@ struct PhiloxArgs {
   int32_t* actions;
 };
 
+// Counter-based-sampler mode only: the step of the device-resident synthetic environments inside the heads launch.
+// Row i's workgroup samples its own action, so it also does environment i's bookkeeping (reward clip, mask, episode
+// totals) -- nothing crosses workgroups -- and workgroups [batch, batch + batch*PRE_BANDS) shift the observation
+// stacks (the new frame does not depend on the action).
+struct SynthStepArgs {
+  int enabled;
+  uint64_t seed;
+  uint32_t thresh;
+  const uint32_t* stack_in;
+  uint32_t* stack_out;
+  float *rewards, *masks, *ep_reward;
+  int32_t* ep_len;
+  FinishedRing* fin;
+};
+
 __device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                  uint32_t k1) {
 #pragma unroll
@@ -89,11 +105,24 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
                                                         float* __restrict__ logits_ws, float* __restrict__ probs_ws,
                                                         float* __restrict__ values_ws, float* __restrict__ logits_out,
                                                         float* __restrict__ probs_out, float* __restrict__ values_out,
-                                                        const PhiloxArgs ph) {
+                                                        const PhiloxArgs ph, const int batch, const SynthStepArgs st) {
   constexpr int JPT = H / 256;
   constexpr int NV = AP + 1;                 // A logits (padded) + value
   const int i = blockIdx.x;
   const int tid = threadIdx.x;
+  float ep_reward0 = 0.f;
+  int32_t ep_len0 = 0;
+  if (st.enabled) {
+    if (i >= batch) {
+      const uint64_t id = (ph.step_base ? *ph.step_base : 0ull) + ph.step_off + 1ull;
+      synth_shift_band(st.seed, ph.env_offset, id, st.thresh, i - batch, st.stack_in, st.stack_out);
+      return;
+    }
+    if (tid == 0) {                          // the running totals do not depend on the action: request them now
+      ep_reward0 = st.ep_reward[i];
+      ep_len0 = st.ep_len[i];
+    }
+  }
   HEADS_STAMP_INIT();
   HEADS_STAMP(0);
   // ---- every independent load first ---------------------------------------------------------------
@@ -173,6 +202,11 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     values_ws[i] = lg[AP];
     if (values_out) values_out[i] = lg[AP];
     if (ph.enabled) ph.actions[i] = act;
+    if (st.enabled) {
+      const uint64_t id = step0 + ph.step_off + 1ull;
+      const uint32_t key = synth_key(st.seed, ph.env_offset + (uint32_t)i, id);
+      synth_bookkeep_with(key, i, act, st.thresh, ep_reward0, ep_len0, st.rewards, st.masks, st.ep_reward, st.ep_len, st.fin);
+    }
   }
   HEADS_STAMP(4);
 }

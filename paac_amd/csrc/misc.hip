@@ -1,6 +1,7 @@
 // HBM-bound kernels of the PAAC hot path on gfx950: n-step returns, lr schedule, samplers,
 // frame preprocessing / stacking, device-resident synthetic environments, clip + RMSProp.
 #include "common.h"
+#include "synth_dev.h"
 
 namespace paac {
 
@@ -411,7 +412,6 @@ __device__ __forceinline__ uint32_t gray601(uint32_t r, uint32_t g, uint32_t b) 
   return (r * 19595u + g * 38470u + b * 7471u + 32768u) >> 16;
 }
 
-constexpr int PRE_BANDS = 7;           // 84 rows = 7 bands x 12 rows
 constexpr int PRE_ROWS_PER_BAND = 12;  // 3 iterations of 4 waves
 
 // grid (N, 7), 256 threads.  Each wave stages the two source rows of one output row in LDS with
@@ -473,59 +473,7 @@ __global__ __launch_bounds__(256) void preprocess_stack_kernel(const uint8_t* __
 }
 
 // =============================================================================================
-// Synthetic environments (spec: paac_amd/synthetic.py).
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ uint32_t synth_key(uint64_t seed, uint32_t env, uint64_t id) {
-  uint32_t k = lowbias32((uint32_t)seed ^ lowbias32(env + 0x9E3779B9u));
-  k = lowbias32(k ^ (uint32_t)(seed >> 32) ^ lowbias32((uint32_t)id * 0x85EBCA6Bu + (uint32_t)(id >> 32) + 0x7F4A7C15u));
-  return k;
-}
-__device__ __forceinline__ uint32_t synth_word(uint32_t key, uint32_t w) { return lowbias32(key + w * 0x9E3779B9u + 0x165667B1u); }
-
-struct FinishedRing {
-  int32_t count;
-  int32_t pad;
-  float reward[4096];
-  int32_t len[4096];
-};
-
-// Per-env bookkeeping shared by both paths: emulator_runner.py:30-31 + paac.py:119-138.  ep_reward0 / ep_len0 = the
-// running totals before this step (callers that have something to wait for load them early).
-__device__ __forceinline__ bool synth_bookkeep_with(uint32_t key, int e, int act, uint32_t thresh, float ep_reward0,
-                                                    int32_t ep_len0, float* rewards_out, float* masks_out,
-                                                    float* ep_reward, int32_t* ep_len, FinishedRing* fin) {
-  const float table[5] = {-2.f, 0.f, 0.f, 1.f, 3.f};
-  const uint32_t hr = lowbias32(key ^ 0xA511E9B3u);
-  const float r = table[(hr % 5u + (uint32_t)act) % 5u];
-  const bool term = lowbias32(key ^ 0x3C6EF372u) < thresh;
-  rewards_out[e] = fminf(fmaxf(r, -1.f), 1.f);   // actor_learner.py:95-101
-  masks_out[e] = term ? 0.f : 1.f;               // paac.py:119
-  const float tot = ep_reward0 + r;
-  const int len = ep_len0 + 1;
-  if (term) {
-    if (fin) {
-      const int slot = atomicAdd(&fin->count, 1) & 4095;
-      fin->reward[slot] = tot;
-      fin->len[slot] = len;
-    }
-    ep_reward[e] = 0.f;
-    ep_len[e] = 0;
-  } else {
-    ep_reward[e] = tot;
-    ep_len[e] = len;
-  }
-  return term;
-}
-__device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_t* actions, uint32_t thresh,
-                                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
-                                               FinishedRing* fin) {
-  return synth_bookkeep_with(key, e, actions ? actions[e] : 0, thresh, ep_reward[e], ep_len[e], rewards_out, masks_out,
-                             ep_reward, ep_len, fin);
-}
-
+// Synthetic environments (spec: paac_amd/synthetic.py); device helpers in synth_dev.h.
 // Path A: one new 84x84 plane per step.  grid (N, 7), 256 threads; one dword (pixel x 4 channels) per thread-iteration.
 __global__ __launch_bounds__(256) void synth_step_a_kernel(uint64_t seed, uint32_t env_offset, int N,
                                                            const int32_t* __restrict__ actions, uint32_t thresh,
@@ -592,20 +540,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     MISC_STAMP(8);
     return;
   }
-  const int e = (blockIdx.x - 1) / PRE_BANDS;
-  const int band = (blockIdx.x - 1) % PRE_BANDS;
-  const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
-  const bool reset = lowbias32(key ^ 0x3C6EF372u) < thresh;
-  constexpr int PIX_PER_BAND = OBS_PIX / PRE_BANDS;  // 1008
-  for (int i = threadIdx.x; i < PIX_PER_BAND; i += 256) {
-    const int p = band * PIX_PER_BAND + i;
-    const int y = p / 84, x = p - y * 84;
-    const uint32_t w = synth_word(key, (uint32_t)(y * 21 + (x >> 2)));
-    const uint32_t nv = (w >> (8 * (x & 3))) & 255u;
-    const long pix = (long)e * OBS_PIX + p;
-    const uint32_t old = reset ? 0u : stack_in[pix];
-    stack_out[pix] = (old >> 8) | (nv << 24);
-  }
+  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out);
 }
 
 // Path B, stage 1: generate the two raw 210x160 gray frames of this step + bookkeeping.

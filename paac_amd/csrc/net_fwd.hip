@@ -84,7 +84,7 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 template <class NT>
 static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
-                        float* probs, float* values, const PhiloxArgs& ph, hipStream_t s) {
+                        float* probs, float* values, const PhiloxArgs& ph, const SynthStepArgs& st, hipStream_t s) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[wsi];
   ctx->last_ws = wsi;
@@ -134,8 +134,11 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   }
   {
     ProfScope ps(ctx, F_HEADS_FWD, batch, s);
-    launch_heads_fwd<NT::H>(A, dim3(batch), s, (const float*)W.fc_slab, splits, (long)batch * NT::H, bf, wa, ba, wc, bc,
-                            A, W.h, W.logits, W.probs, W.values, logits, probs, values, ph);
+    SynthStepArgs stl = st;
+    if (stl.enabled) stl.stack_in = reinterpret_cast<const uint32_t*>(states);   // the stacks just observed
+    launch_heads_fwd<NT::H>(A, dim3(stl.enabled ? batch + batch * PRE_BANDS : batch), s, (const float*)W.fc_slab, splits,
+                            (long)batch * NT::H, bf, wa, ba, wc, bc, A, W.h, W.logits, W.probs, W.values, logits, probs,
+                            values, ph, batch, stl);
   }
   return 0;
 }
@@ -144,14 +147,19 @@ int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* st
                    float* probs, float* values, hipStream_t s) {
   PhiloxArgs ph;
   memset(&ph, 0, sizeof(ph));
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
-  return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, s);
+    return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
+  return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
 }
 
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
                           float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
-                          uint32_t env_offset, int32_t* actions, hipStream_t s) {
+                          uint32_t env_offset, int32_t* actions, const SynthStepArgs* step, hipStream_t s) {
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
+  if (step) st = *step;
   PhiloxArgs ph;
   ph.enabled = 1;
   ph.seed = seed;
@@ -160,8 +168,28 @@ int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* sta
   ph.env_offset = env_offset;
   ph.actions = actions;
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
-  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, s);
+    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, st, s);
+  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, st, s);
+}
+
+int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
+                               float* values, uint64_t seed, const uint64_t* step_base, uint64_t step_off,
+                               uint32_t env_offset, int32_t* actions, uint64_t env_seed, uint32_t thresh,
+                               uint8_t* stack_out, float* rewards, float* masks, float* ep_reward, int32_t* ep_len,
+                               void* finished, hipStream_t s) {
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
+  st.enabled = 1;
+  st.seed = env_seed;
+  st.thresh = thresh;
+  st.stack_out = reinterpret_cast<uint32_t*>(stack_out);
+  st.rewards = rewards;
+  st.masks = masks;
+  st.ep_reward = ep_reward;
+  st.ep_len = ep_len;
+  st.fin = reinterpret_cast<FinishedRing*>(finished);
+  return launch_forward_sample(ctx, params, states, batch, probs, values, seed, step_base, step_off, env_offset, actions, &st,
+                               s);
 }
 
 #ifdef PAAC_DMM_STAMPS

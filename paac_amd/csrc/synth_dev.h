@@ -1,0 +1,82 @@
+// Device helpers of the synthetic environments (spec: paac_amd/synthetic.py), shared by the env-step kernels
+// (csrc/misc.hip) and the heads kernel that absorbs the step in the counter-based-sampler mode (csrc/heads.h).
+#pragma once
+#include "common.h"
+
+namespace paac {
+
+constexpr int PRE_BANDS = 7;           // 84 rows = 7 bands x 12 rows
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t synth_key(uint64_t seed, uint32_t env, uint64_t id) {
+  uint32_t k = lowbias32((uint32_t)seed ^ lowbias32(env + 0x9E3779B9u));
+  k = lowbias32(k ^ (uint32_t)(seed >> 32) ^ lowbias32((uint32_t)id * 0x85EBCA6Bu + (uint32_t)(id >> 32) + 0x7F4A7C15u));
+  return k;
+}
+__device__ __forceinline__ uint32_t synth_word(uint32_t key, uint32_t w) { return lowbias32(key + w * 0x9E3779B9u + 0x165667B1u); }
+
+struct FinishedRing {
+  int32_t count;
+  int32_t pad;
+  float reward[4096];
+  int32_t len[4096];
+};
+
+// Per-env bookkeeping shared by both paths: emulator_runner.py:30-31 + paac.py:119-138.  ep_reward0 / ep_len0 = the
+// running totals before this step (callers that have something to wait for load them early).
+__device__ __forceinline__ bool synth_bookkeep_with(uint32_t key, int e, int act, uint32_t thresh, float ep_reward0,
+                                                    int32_t ep_len0, float* rewards_out, float* masks_out,
+                                                    float* ep_reward, int32_t* ep_len, FinishedRing* fin) {
+  const float table[5] = {-2.f, 0.f, 0.f, 1.f, 3.f};
+  const uint32_t hr = lowbias32(key ^ 0xA511E9B3u);
+  const float r = table[(hr % 5u + (uint32_t)act) % 5u];
+  const bool term = lowbias32(key ^ 0x3C6EF372u) < thresh;
+  rewards_out[e] = fminf(fmaxf(r, -1.f), 1.f);   // actor_learner.py:95-101
+  masks_out[e] = term ? 0.f : 1.f;               // paac.py:119
+  const float tot = ep_reward0 + r;
+  const int len = ep_len0 + 1;
+  if (term) {
+    if (fin) {
+      const int slot = atomicAdd(&fin->count, 1) & 4095;
+      fin->reward[slot] = tot;
+      fin->len[slot] = len;
+    }
+    ep_reward[e] = 0.f;
+    ep_len[e] = 0;
+  } else {
+    ep_reward[e] = tot;
+    ep_len[e] = len;
+  }
+  return term;
+}
+__device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_t* actions, uint32_t thresh,
+                                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
+                                               FinishedRing* fin) {
+  return synth_bookkeep_with(key, e, actions ? actions[e] : 0, thresh, ep_reward[e], ep_len[e], rewards_out, masks_out,
+                             ep_reward, ep_len, fin);
+}
+
+// Frame shift of one (env, band) unit of path A: push the step's new 84x84 plane into the 4-deep history
+// (one dword = the 4 channels of a pixel).  unit = env * PRE_BANDS + band; 256 threads.
+__device__ __forceinline__ void synth_shift_band(uint64_t seed, uint32_t env_offset, uint64_t id, uint32_t thresh, int unit,
+                                                 const uint32_t* __restrict__ stack_in, uint32_t* __restrict__ stack_out) {
+  const int e = unit / PRE_BANDS;
+  const int band = unit % PRE_BANDS;
+  const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
+  const bool reset = lowbias32(key ^ 0x3C6EF372u) < thresh;
+  constexpr int PIX_PER_BAND = OBS_PIX / PRE_BANDS;  // 1008
+  for (int i = threadIdx.x; i < PIX_PER_BAND; i += 256) {
+    const int p = band * PIX_PER_BAND + i;
+    const int y = p / 84, x = p - y * 84;
+    const uint32_t w = synth_word(key, (uint32_t)(y * 21 + (x >> 2)));
+    const uint32_t nv = (w >> (8 * (x & 3))) & 255u;
+    const long pix = (long)e * OBS_PIX + p;
+    const uint32_t old = reset ? 0u : stack_in[pix];
+    stack_out[pix] = (old >> 8) | (nv << 24);
+  }
+}
+
+}  // namespace paac

@@ -93,6 +93,32 @@ class Context(object):
                                                 int(env_offset), _ptr(actions, torch.int32, B, "actions"), _stream()),
                    "paac_forward_sample")
 
+    def forward_sample_synth_step(self, params, states, seed, step_base_dev, step_offset, env_offset, actions, env_seed,
+                                  terminal_threshold, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None,
+                                  probs=None, values=None):
+        """forward + counter-based sampler + synthetic env step (path A) in the forward's five launches."""
+        B = states.shape[0]
+        A = self.num_actions
+        if tuple(states.shape[1:]) != OBS_SHAPE or tuple(stack_out.shape) != tuple(states.shape):
+            raise ValueError("states / stack_out must be [B,84,84,4] uint8, got %s / %s" %
+                             (tuple(states.shape), tuple(stack_out.shape)))
+        if not (0 < B <= self.max_batch):
+            raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
+        if states.data_ptr() == stack_out.data_ptr():
+            raise ValueError("the step cannot shift the stacks in place")
+        if finished is not None and finished.numel() * finished.element_size() < FINISHED_RING_BYTES:
+            raise ValueError("finished ring too small")
+        _lib.check(self.lib.paac_forward_sample_synth_step(
+            self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+            _ptr(states, torch.uint8, B * 28224, "states"), B, _ptr(probs, torch.float32, B * A, "probs", True),
+            _ptr(values, torch.float32, B, "values", True), int(seed), _ptr(step_base_dev, torch.int64, 1, "step_base", True),
+            int(step_offset), int(env_offset), _ptr(actions, torch.int32, B, "actions"), int(env_seed),
+            int(terminal_threshold), _ptr(stack_out, torch.uint8, B * 28224, "stack_out"),
+            _ptr(rewards_out, torch.float32, B, "rewards_out"), _ptr(masks_out, torch.float32, B, "masks_out"),
+            _ptr(ep_reward, torch.float32, B, "ep_reward"), _ptr(ep_len, torch.int32, B, "ep_len"),
+            ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),
+            "paac_forward_sample_synth_step")
+
     def train_forward(self, params, states, values=None):
         B = states.shape[0]
         if tuple(states.shape[1:]) != OBS_SHAPE:

@@ -105,6 +105,13 @@ class DeviceRollout(object):
             if self.sampler == "numpy":
                 L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
                 hip_ops.sample_mt(self.probs, self.mt_state, self.mt_scratch, self.actions[t])
+            elif self.raw is None:      # counter-based sampler AND the env step inside the heads kernel
+                L.ctx.forward_sample_synth_step(params, st[t], self.sampler_seed, self.tick, t, self.env_offset,
+                                                self.actions[t], self.env_spec["seed"],
+                                                self.env_spec["terminal_threshold"], st[t + 1], self.rewards[t],
+                                                self.masks[t], self.ep_reward, self.ep_len, self.finished,
+                                                probs=self.probs, values=self.values[t])
+                continue
             else:       # counter-based sampler fused into the heads kernel
                 L.ctx.forward_sample(params, st[t], self.sampler_seed, self.tick, t, self.env_offset,
                                      self.actions[t], probs=self.probs, values=self.values[t])

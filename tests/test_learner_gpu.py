@@ -197,3 +197,49 @@ def test_batched_graph_launches_equal_single_cycles():
     assert np.array_equal(a0, a1) and np.array_equal(s0, s1)
     for k in p0:
         assert np.array_equal(p0[k], p1[k]), k
+
+
+@pytest.mark.parametrize("arch,A,N", [("NATURE", 4, 32), ("NIPS", 18, 8), ("NATURE", 6, 300)])
+def test_philox_step_inside_heads_equals_separate_calls(arch, A, N):
+    """paac_forward_sample_synth_step (row i's heads workgroup also does environment i's bookkeeping, extra workgroups
+    shift the stacks) == paac_forward_sample followed by paac_synth_step, bit for bit, over consecutive steps."""
+    from paac_amd import hip_ops
+    from paac_amd.synthetic import terminal_threshold
+    arch_id = {"NIPS": 0, "NATURE": 1}[arch]
+    ctx = hip_ops.Context(arch_id, A, max_batch=N)
+    host = onet.init_params(arch, A, np.random.RandomState(1), dtype=np.float32)
+    flat = np.zeros(ctx.layout["total"], dtype=np.float32)
+    for t in ctx.layout["tensors"]:
+        flat[t["offset"]:t["offset"] + t["size"]] = host[t["name"]].reshape(-1)
+    p = torch.from_numpy(flat).cuda()
+    env_seed, sampler_seed, off, thr = 5, 77, 3, terminal_threshold(0.15)
+
+    def fresh():
+        d = dict(s0=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 s1=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 act=torch.zeros(N, dtype=torch.int32, device="cuda"), probs=torch.zeros((N, A), device="cuda"),
+                 val=torch.zeros(N, device="cuda"), rew=torch.zeros(N, device="cuda"), msk=torch.zeros(N, device="cuda"),
+                 ep_r=torch.zeros(N, device="cuda"), ep_l=torch.zeros(N, dtype=torch.int32, device="cuda"),
+                 fin=torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device="cuda"),
+                 tick=torch.zeros(1, dtype=torch.int64, device="cuda"))
+        hip_ops.synth_reset(env_seed, off, d["s0"], None)
+        return d
+
+    a, b = fresh(), fresh()
+    for step in range(10):
+        ctx.forward_sample_synth_step(p, a["s0"], sampler_seed, a["tick"], 0, off, a["act"], env_seed, thr, a["s1"],
+                                      a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"], probs=a["probs"], values=a["val"])
+        ctx.forward_sample(p, b["s0"], sampler_seed, b["tick"], 0, off, b["act"], probs=b["probs"], values=b["val"])
+        hip_ops.synth_step(env_seed, off, b["act"], thr, b["tick"], 0, b["s0"], b["s1"], b["rew"], b["msk"], b["ep_r"],
+                           b["ep_l"], b["fin"])
+        torch.cuda.synchronize()
+        for k in ("probs", "val", "act", "rew", "msk", "ep_r", "ep_l", "s1"):
+            assert torch.equal(a[k], b[k]), "step %d: %s differs" % (step, k)
+        fa, fb = a["fin"].cpu().numpy(), b["fin"].cpu().numpy()
+        n = int(fa[0])
+        assert fa[0] == fb[0] and sorted(fa[2:2 + n].tolist()) == sorted(fb[2:2 + n].tolist())
+        for d in (a, b):
+            hip_ops.counter_add(d["tick"], 1)
+            d["s0"], d["s1"] = d["s1"], d["s0"]
+    assert int(a["fin"][0]) > 0
+    ctx.close()
