@@ -20,7 +20,12 @@ shutil.copy(stats, "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
 trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Start_Timestamp']))
 marks = [i for i, r in enumerate(rows) if 'rmsprop_kernel' in r['Kernel_Name']]
-k = len(marks) // 3          # a steady-state cycle of the hipGraph phase (the tail of the trace is the eager, event-bracketed pass)
+k0 = len(marks) // 3         # steady-state part of the hipGraph phase (the tail of the trace is the eager, event-bracketed pass)
+# the profiler occasionally stalls the queue for milliseconds while it drains its buffers: take the shortest of a few
+# consecutive cycles
+def wall(k):
+    return int(rows[marks[k + 1] + 1]['Start_Timestamp']) - int(rows[marks[k] + 1]['Start_Timestamp'])
+k = min(range(k0, min(k0 + 8, len(marks) - 2)), key=wall)
 i0, i1 = marks[k] + 1, marks[k + 1] + 1
 t0 = int(rows[i0]['Start_Timestamp'])
 with open("profiles/%s_cycle_timeline.txt" % tag, "w") as f:
