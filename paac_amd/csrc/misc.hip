@@ -158,6 +158,66 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
 constexpr int MT_LDS_D = 1024;
 constexpr int MT_LDS_BLK = 5;   // 624 + 2*1024 u32 <= 5*624
 constexpr int MT_TAB_MAX = 16384;
+// Phase 4a of sample_mt_body: jh(e, o) = first category hit when environment e starts drawing at stream offset o, for
+// every reachable (e, o).  Environment e has e (J-1) + 1 reachable offsets (every earlier environment drew between 1
+// and J doubles), so e is paired with N-1-e -- every pair has (N-1)(J-1) + 2 entries -- and each pair is filled by one
+// 16-thread group.  JC > 0: J as a compile-time constant, thresholds in registers, the J draws of an entry requested
+// before the compares.  JC == 0: any J, thresholds re-read per entry.
+template <int JC>
+__device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double* u_buf, unsigned char* jh_tab, int N, int D,
+                                              int Jdyn = 0) {
+  const int J = JC > 0 ? JC : Jdyn;
+  constexpr int JR = JC > 0 ? JC : 1;
+  const int tid = threadIdx.x;
+  const int grp = tid >> 4, k = tid & 15;
+  const int npairs = (N + 1) / 2;
+  auto threshold = [&](int e, int j, double& thr, bool& inv) {   // hit(U) == ((U > thr) != inv)
+    const double pj = pj_buf[e * J + j];
+    inv = !(pj <= 0.5);
+    thr = inv ? 1.0 - (1.0 - pj) : 1.0 - pj;
+  };
+  for (int pe = grp; pe < npairs; pe += 16) {
+    const int ea = pe, eb = N - 1 - pe;
+    const int cnt_a = ea * (J - 1) + 1, cnt_b = (eb != ea) ? eb * (J - 1) + 1 : 0;
+    const int base_a = ea + (J - 1) * ea * (ea - 1) / 2, base_b = eb + (J - 1) * eb * (eb - 1) / 2;
+    double thr_a[JR], thr_b[JR];
+    bool inv_a[JR], inv_b[JR];
+    if constexpr (JC > 0) {
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {
+        threshold(ea, j, thr_a[j], inv_a[j]);
+        threshold(eb, j, thr_b[j], inv_b[j]);
+      }
+    }
+    for (int c = k; c < cnt_a + cnt_b; c += 16) {
+      const bool first = c < cnt_a;
+      const int e = first ? ea : eb;
+      const int idx = first ? c : c - cnt_a;   // table slot of the pair member
+      const int o = e + idx;                   // stream offset it stands for
+      int jh = J;
+      if constexpr (JC > 0) {
+        double U[JR];
+#pragma unroll
+        for (int j = 0; j < JC; ++j) U[j] = u_buf[o + j < D ? o + j : D - 1];
+#pragma unroll
+        for (int j = JC - 1; j >= 0; --j) {
+          const double thr = first ? thr_a[j] : thr_b[j];
+          const bool inv = first ? inv_a[j] : inv_b[j];
+          if ((U[j] > thr) != inv) jh = j;
+        }
+      } else {
+        for (int j = J - 1; j >= 0; --j) {
+          double thr;
+          bool inv;
+          threshold(e, j, thr, inv);
+          if ((u_buf[o + j < D ? o + j : D - 1] > thr) != inv) jh = j;
+        }
+      }
+      jh_tab[(first ? base_a : base_b) + idx] = (unsigned char)jh;
+    }
+  }
+}
+
 template <bool LDSPATH>
 __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
@@ -257,58 +317,18 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     const long tab_entries = (long)N + (long)(J - 1) * N * (N - 1) / 2;
     if (tab_entries <= MT_TAB_MAX && N <= 256) {
       if (!any_zero) {     // set in phase 1, visible since the barrier after phase 3
-        // Table fill: environment e has e (J-1) + 1 reachable offsets, so e is paired with N-1-e -- every pair has
-        // (N-1)(J-1) + 2 entries -- and each pair is filled by one 16-thread group.  An entry costs J LDS reads of the
-        // draws (the thresholds sit in registers for J <= JR), all issued before the compares.
-        constexpr int JR = 8;
-        const int grp = tid >> 4, k = tid & 15;
-        const int npairs = (N + 1) / 2;
-        for (int pe = grp; pe < npairs; pe += 16) {
-          const int ea = pe, eb = N - 1 - pe;
-          const int cnt_a = ea * (J - 1) + 1, cnt_b = (eb != ea) ? eb * (J - 1) + 1 : 0;
-          const int base_a = ea + (J - 1) * ea * (ea - 1) / 2, base_b = eb + (J - 1) * eb * (eb - 1) / 2;
-          double thr_a[JR], thr_b[JR];
-          bool inv_a[JR], inv_b[JR];
-          auto threshold = [&](int e, int j, double& thr, bool& inv) {   // hit(U) == ((U > thr) != inv)
-            const double pj = pj_buf[e * J + j];
-            inv = !(pj <= 0.5);
-            thr = inv ? 1.0 - (1.0 - pj) : 1.0 - pj;
-          };
-#pragma unroll
-          for (int j = 0; j < JR; ++j) {
-            if (j < J) {
-              threshold(ea, j, thr_a[j], inv_a[j]);
-              threshold(eb, j, thr_b[j], inv_b[j]);
-            }
-          }
-          for (int c = k; c < cnt_a + cnt_b; c += 16) {
-            const bool first = c < cnt_a;
-            const int e = first ? ea : eb;
-            const int idx = first ? c : c - cnt_a;   // table slot of the pair member
-            const int o = e + idx;                   // stream offset it stands for
-            int jh = J;
-            if (J <= JR) {
-              double U[JR];
-#pragma unroll
-              for (int j = 0; j < JR; ++j) U[j] = (j < J) ? u_buf[o + j < D ? o + j : D - 1] : 0.0;
-#pragma unroll
-              for (int j = JR - 1; j >= 0; --j) {
-                if (j < J) {
-                  const double thr = first ? thr_a[j] : thr_b[j];
-                  const bool inv = first ? inv_a[j] : inv_b[j];
-                  if ((U[j] > thr) != inv) jh = j;
-                }
-              }
-            } else {
-              for (int j = J - 1; j >= 0; --j) {
-                double thr;
-                bool inv;
-                threshold(e, j, thr, inv);
-                if ((u_buf[o + j < D ? o + j : D - 1] > thr) != inv) jh = j;
-              }
-            }
-            jh_tab[(first ? base_a : base_b) + idx] = (unsigned char)jh;
-          }
+        // Table fill (mt_fill_table): the category count is dispatched to a compile-time constant, so the fill has
+        // no branch per category
+        switch (J) {
+          case 1: mt_fill_table<1>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 2: mt_fill_table<2>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 3: mt_fill_table<3>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 4: mt_fill_table<4>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 5: mt_fill_table<5>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 6: mt_fill_table<6>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 7: mt_fill_table<7>(pj_buf, u_buf, jh_tab, N, D); break;
+          case 8: mt_fill_table<8>(pj_buf, u_buf, jh_tab, N, D); break;
+          default: mt_fill_table<0>(pj_buf, u_buf, jh_tab, N, D, J); break;
         }
         __syncthreads();
         MISC_STAMP(5);
