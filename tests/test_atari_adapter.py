@@ -183,3 +183,41 @@ def test_device_preprocessing_loop_equals_host_loop():
     for c, (a, b) in enumerate(zip(feeds[False], feeds[True])):
         assert np.array_equal(a["states"], b["states"]), "cycle %d: observations differ" % c
         assert np.array_equal(a["actions"], b["actions"]) and np.array_equal(a["y"], b["y"])
+
+
+def test_evaluation_loop_freezes_finished_environments(monkeypatch):
+    """paac_amd.test.evaluate: every environment plays ONE episode; its score stops changing once it is over (the
+    reference's loop, test.py:77-83, keeps stepping and adding until all happen to finish on the same step)."""
+    import paac_amd.test as harness
+    from paac_amd.atari_emulator import AtariEmulator
+
+    class Creator(object):
+        num_actions = 4
+
+        def __init__(self):
+            self.made = []
+
+        def create_environment(self, i):
+            env = AtariEmulator(i, emu_args(random_start=False), ale=FakeALE(episode_frames=60 + 24 * i))
+            self.made.append(env)
+            return env
+
+    steps = {"n": 0}
+
+    def fake_choose(network, num_actions, states, session):
+        steps["n"] += 1
+        assert states.shape == (3, 84, 84, 4) and states.dtype == np.uint8
+        idx = np.full(3, steps["n"] % num_actions)
+        return np.eye(num_actions)[idx], np.zeros(3), np.full((3, num_actions), 0.25)
+
+    monkeypatch.setattr(harness.PAACLearner, "choose_next_actions", staticmethod(fake_choose))
+    random.seed(2)
+    creator = Creator()
+    rewards = harness.evaluate(network=None, env_creator=creator, session=None, test_count=3, noops=4)
+    assert rewards.shape == (3,) and rewards.dtype == np.float32
+    # episodes of 60, 84, 108 emulator frames: 16 reset frames, then 4 per step (no-ops included) -> the longest one
+    # decides how many policy steps were taken, the shorter ones were not stepped past their end
+    assert all(env.ale.game_over() for env in creator.made)
+    frames = [env.ale.t - env.ale.start for env in creator.made]
+    assert frames == [60, 84, 108], frames
+    assert 10 <= steps["n"] <= 23
