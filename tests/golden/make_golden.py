@@ -158,13 +158,19 @@ CONFIGS = [
     ("pong_n8_t5_a6", 8, 5, 6, 2, 3, 42),
     ("breakout_n8_t5_a4", 8, 5, 4, 2, 3, 43),
     ("seaquest_n4_t20_a18", 4, 20, 18, 2, 2, 44),
+    # SURVEY.md Appendix B matrix: the headline shard (32 envs, 8 workers) and a long-rollout A=18 case
+    ("breakout_n32_t5_a4", 32, 5, 4, 8, 3, 45),
+    ("seaquest_n16_t20_a18", 16, 20, 18, 4, 3, 46),
 ]
 
 if __name__ == "__main__":
     import warnings
     warnings.simplefilter("ignore", DeprecationWarning)
     install_tf_stub()
+    only = set(sys.argv[1:])
     for name, N, T, A, W, cycles, seed in CONFIGS:
+        if only and name not in only:
+            continue
         out = capture(N, T, A, W, cycles, seed)
         path = os.path.join(HERE, "rollout_%s.npz" % name)
         np.savez_compressed(path, **out)
