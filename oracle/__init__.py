@@ -5,7 +5,7 @@ reference implements in paac.py / actor_learner.py / networks.py /
 policy_v_network.py / environment.py / atari_emulator.py.  Each function cites
 the reference file:line it follows.
 
-Rules (enforced by tests/test_no_oracle_in_product.py):
+Rules (enforced by tests/test_cabi_and_hostlogic.py::test_product_never_imports_oracle):
   * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
     import anything from here;
   * nothing under paac_amd/ imports it: the product path is HIP-only and fails

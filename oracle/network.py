@@ -15,8 +15,12 @@ Constants TF leaves implicit are taken from pretrained/*/checkpoints/*.meta
 global_norm = sqrt(sum g^2), clip factor = c * min(1/gn, 1/c).
 
 PARITY UNPINNED at the TensorFlow boundary: the reference holds no golden
-vectors for these ops; this restatement is cross-checked against torch float64
-autograd in tests/test_oracle_network.py.
+vectors for these ops.  What it does hold -- the serialized NIPS training graph
+pretrained/breakout/checkpoints/-80000000.meta -- pins the STRUCTURE node by node
+(tests/test_meta_graph_pin.py: op types, wiring, Conv2D strides/padding/layout,
+every constant, the clip formula, ApplyRMSProp inputs, slot and weight
+initialisers, checkpoint names and shapes); the restatement's values are
+cross-checked against torch float64 autograd in tests/test_oracle_network.py.
 """
 import numpy as np
 

@@ -6,7 +6,9 @@ Follows:
   environment.py:58-75     ObservationPool: write slot `idx`, idx=(idx+1)%4, read-out rotated so
                            channel 0 is the oldest and channel 3 the newest frame
 scipy.misc.imresize(interp='nearest') == PIL Image.resize((84,84), NEAREST) (third-party,
-PIL is installed; the LUTs below are regenerated from PIL in tests/test_oracle_preprocess.py).
+PIL is installed; the LUTs below are regenerated from PIL in
+tests/test_cabi_and_hostlogic.py::test_oracle_luts_regenerate_from_pil and pinned to the reference's own
+stacked states by tests/test_oracle_golden.py).
 The reference converts RGB->gray inside ALE (atari_emulator.py:51; third-party C++, absent):
 `rgb_to_gray` is the build's own spec (ITU-R 601 fixed point == PIL convert('L')); parity unpinned.
 """

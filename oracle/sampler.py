@@ -8,7 +8,8 @@
 2. `sample_mt_restated` restates what numpy's legacy multinomial does for n=1
    in terms of raw 53-bit MT19937 doubles; it is what the
    HIP kernel implements and is checked against (1) in
-   tests/test_oracle_sampler.py.
+   tests/test_oracle_golden.py (both modes replay the reference capture) and
+   tests/test_hip_misc.py::test_sampler_mt_matches_numpy.
 3. `philox4x32` / `sample_philox` restate the build's own counter-based
    throughput sampler (no reference counterpart: parity is to this spec only).
 """

@@ -129,38 +129,51 @@ class ActorLearner(object):
     def _allreduce_grad(self):
         parallel.allreduce_sum_(self.grad)
 
-    # -- reference methods ---------------------------------------------------------------------------
+    # -- reference methods (actor_learner.py:89-127): same names and behaviour ------------------------------
     def save_vars(self, force=False):
-        if force or self.global_step - self.last_saving_step >= CHECKPOINT_INTERVAL:
-            self.last_saving_step = self.global_step
-            self.network_saver.save(self.session, self.network_checkpoint_folder, global_step=self.last_saving_step)
-            self.optimizer_saver.save(self.session, self.optimizer_checkpoint_folder, global_step=self.last_saving_step)
+        """Network + optimizer checkpoints once CHECKPOINT_INTERVAL global steps have passed since the last one (or
+        when forced).  Data parallel: the replicas are identical, rank 0 writes, every rank keeps the same cadence."""
+        due = force or (self.global_step - self.last_saving_step) >= CHECKPOINT_INTERVAL
+        if not due:
+            return
+        self.last_saving_step = self.global_step
+        self._sync_device()                    # nothing in flight: weights, rms and mom belong to the same update
+        if parallel.rank() == 0:
+            for saver, folder in ((self.network_saver, self.network_checkpoint_folder),
+                                  (self.optimizer_saver, self.optimizer_checkpoint_folder)):
+                saver.save(self.session, folder, global_step=self.last_saving_step)
+        parallel.barrier()
+
+    def _sync_device(self):
+        torch.cuda.synchronize(self.torch_device)
 
     def rescale_reward(self, reward):
-        """ Clip immediate reward """
-        if reward > 1.0:
-            reward = 1.0
-        elif reward < -1.0:
-            reward = -1.0
-        return reward
+        """Immediate reward clipped to [-1, 1] (actor_learner.py:95-101)."""
+        return min(1.0, max(-1.0, reward))
 
     def init_network(self):
-        if not os.path.exists(self.network_checkpoint_folder):
-            os.makedirs(self.network_checkpoint_folder)
-        if not os.path.exists(self.optimizer_checkpoint_folder):
-            os.makedirs(self.optimizer_checkpoint_folder)
-        last_saving_step = self.network.init(self.network_checkpoint_folder, self.network_saver, self.session)
-        path = Saver.latest_checkpoint(self.optimizer_checkpoint_folder)
-        if path is not None:
+        """Restore the latest network / optimizer checkpoints if present, else initialise (actor_learner.py:103-117,
+        networks.py:122-135); returns the global step to resume from.  Data parallel: every rank restores (or
+        initialises), then rank 0's weights and optimizer slots are broadcast so the replicas start identical."""
+        for folder in (self.network_checkpoint_folder, self.optimizer_checkpoint_folder):
+            os.makedirs(folder, exist_ok=True)
+        resumed_step = self.network.init(self.network_checkpoint_folder, self.network_saver, self.session)
+        optimizer_checkpoint = Saver.latest_checkpoint(self.optimizer_checkpoint_folder)
+        if optimizer_checkpoint is not None:
             logging.info('Restoring optimizer variables from previous run')
-            self.optimizer_saver.restore(self.session, path)
-        return last_saving_step
+            self.optimizer_saver.restore(self.session, optimizer_checkpoint)
+        if parallel.world_size() > 1:
+            step = torch.tensor([int(resumed_step)], dtype=torch.int64, device=self.torch_device)
+            for t in (self.network.params, self.rms, self.mom, step):
+                parallel.broadcast_(t, src=0)
+            resumed_step = int(step.item())
+        return resumed_step          # like upstream, last_saving_step stays 0: a resumed run checkpoints on its first cycle
 
     def get_lr(self):
-        if self.global_step <= self.lr_annealing_steps:
-            return self.initial_lr - (self.global_step * self.initial_lr / self.lr_annealing_steps)
-        else:
+        """Linear anneal to zero over lr_annealing_steps (actor_learner.py:119-123)."""
+        if self.global_step > self.lr_annealing_steps:
             return 0.0
+        return self.initial_lr - (self.global_step * self.initial_lr / self.lr_annealing_steps)
 
     def cleanup(self):
         self.save_vars(True)

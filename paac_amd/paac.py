@@ -72,8 +72,12 @@ class DeviceRollout(object):
         self.graph_multi = None                        # MULTI consecutive cycles (parity 0 first) in one launch
         self.graph_ua = [None, None]                   # data parallel: update of the previous cycle + graph_a
         self.pending_update = False
-        self.phased = L._world() > 1
-        self.side_group = parallel.side_group() if self.phased else None    # collective: all ranks construct a rollout
+        # data parallel: the cycle is cut at the gradient exchange (graphs around it, collectives between them)
+        self.phased = parallel.collectives_active()
+        # PAAC_ALLREDUCE=single: ONE all-reduce of the whole flat gradient after the full backward (nothing overlapped);
+        # default "split": the fc/heads tail (95 % of the bytes) goes out while the conv backward still computes
+        self.single_exchange = os.environ.get("PAAC_ALLREDUCE", "split") == "single"
+        self.side_group = parallel.side_group() if (self.phased and not self.single_exchange) else None    # collective call
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
@@ -131,7 +135,8 @@ class DeviceRollout(object):
         # one process: whole backward here; data parallel: heads + fc only (phase 1), so that the all-reduce of
         # the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
         L.ctx.loss_backward(params, self.rollout_states(parity), self.actions.view(-1), self.y, self.adv,
-                            L.entropy_beta, L.grad, L.loss_dev, forward_done=True, phase=1 if self.phased else 0)
+                            L.entropy_beta, L.grad, L.loss_dev, forward_done=True,
+                            phase=1 if (self.phased and not self.single_exchange) else 0)
 
     def _backward_conv(self, parity):
         L = self.L
@@ -163,15 +168,15 @@ class DeviceRollout(object):
                 self._update()
 
         with torch.cuda.stream(self.stream):
-            world = self.L._world()
             for parity in (0, 1):
-                self.graph_a[parity] = captured(lambda: cycle(parity, world == 1))
-                if world > 1:
-                    self.graph_conv[parity] = captured(lambda: self._backward_conv(parity))
+                self.graph_a[parity] = captured(lambda: cycle(parity, not self.phased))
+                if self.phased:
+                    if not self.single_exchange:
+                        self.graph_conv[parity] = captured(lambda: self._backward_conv(parity))
                     # the optimizer step of cycle k rides in front of cycle k+1's graph: two graph launches per
                     # cycle around the exchange instead of three (synchronize() flushes a pending step)
                     self.graph_ua[parity] = captured(lambda: (self._update(), cycle(parity, False)))
-            if world > 1:
+            if self.phased:
                 self.graph_b = captured(self._update)
             else:
                 self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
@@ -201,14 +206,14 @@ class DeviceRollout(object):
                     self.capture()
                 if self.phased:
                     (self.graph_ua if self.pending_update else self.graph_a)[self.parity].launch()
-                    self._exchange(self.graph_conv[self.parity].launch)
+                    self._exchange(None if self.single_exchange else self.graph_conv[self.parity].launch)
                     self.pending_update = True
                 else:
                     self.graph_a[self.parity].launch()
             else:
                 self._rollout_and_backward(self.parity)
                 if self.phased:
-                    self._exchange(lambda: self._backward_conv(self.parity))
+                    self._exchange(None if self.single_exchange else (lambda: self._backward_conv(self.parity)))
                 self._update()
         self.parity ^= 1
 
@@ -216,6 +221,11 @@ class DeviceRollout(object):
         """Sum all-reduce of the flat gradient in two pieces: the fc/heads tail goes out (on the collective's own
         stream) while `conv_backward` still computes the conv head on ours; the update waits for both."""
         grad = self.L.grad
+        if conv_backward is None:          # PAAC_ALLREDUCE=single: the backward is complete, one collective
+            work = parallel.allreduce_sum_async(grad)
+            if work is not None:
+                work.wait()
+            return
         tail = parallel.allreduce_sum_async(grad[self.tail_offset:])
         conv_backward()
         # the small conv part goes out on a second communicator: it does not wait for the 6.4 MB one to finish
@@ -290,6 +300,7 @@ class PAACLearner(ActorLearner):
         self.runners = None
         self.rollout = None
         self.metrics = None
+        self.stop_requested = False      # set by the signal handler (train.py); honoured at the next cycle boundary
 
     def _open_metrics(self):
         """metrics.jsonl in the debugging folder (rank 0 only): what the reference sends to TensorBoard."""
@@ -365,7 +376,15 @@ class PAACLearner(ActorLearner):
         metrics = self._open_metrics()
         episodes_seen = 0
         from .actor_learner import CHECKPOINT_INTERVAL
+        since_stop_check = 0
         while self.global_step < self.max_global_steps:
+            if world == 1:
+                if self.stop_requested:
+                    break
+            elif since_stop_check >= 16:       # all ranks must leave at the same cycle (one collective per >= 16 cycles)
+                since_stop_check = 0
+                if parallel.any_rank(self.stop_requested, self.torch_device):
+                    break
             loop_start_time = time.time()
             # as many cycles per call as fit before the next event the reference checks every cycle: the end of
             # training, the progress line (paac.py:172) and the checkpoint (actor_learner.py:89-93)
@@ -378,6 +397,7 @@ class PAACLearner(ActorLearner):
             self.rollout.run_cycles(chunk)
             self.global_step += chunk * steps_per_cycle
             counter += chunk
+            since_stop_check += chunk
             if counter % log_every == 0:
                 self.rollout.synchronize()
                 curr_time = time.time()
@@ -392,9 +412,7 @@ class PAACLearner(ActorLearner):
                     episodes_seen = count
                     self._progress_record(chunk * steps_per_cycle / (curr_time - loop_start_time),
                                           (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
-            if self.global_step - self.last_saving_step >= CHECKPOINT_INTERVAL:
-                self.rollout.synchronize()           # the checkpoint must see the finished update, nothing in flight
-            self.save_vars()
+            self.save_vars()          # _sync_device() flushes the rollout first when a checkpoint is due
         self.rollout.synchronize()
 
     # -- host-environment loop (the reference's structure, kernels instead of session.run) ------------
@@ -450,7 +468,7 @@ class PAACLearner(ActorLearner):
         self.last_feed = None
         metrics = self._open_metrics()
 
-        while self.global_step < self.max_global_steps:
+        while self.global_step < self.max_global_steps and not parallel.any_rank(self.stop_requested, dev):
             loop_start_time = time.time()
             for t in range(T):
                 d_states[t].copy_(current_states())
@@ -505,8 +523,16 @@ class PAACLearner(ActorLearner):
             self.save_vars()
         np.random.set_state(hip_ops.mt_state_to_numpy(mt_state))
 
+    def _sync_device(self):
+        """Everything issued so far has completed -- graph-replayed cycles still running on the rollout's own stream and
+        a data-parallel optimizer step still waiting to ride in front of the next cycle included -- so a checkpoint
+        taken now holds weights, rms and mom of one and the same update."""
+        if self.rollout is not None:
+            self.rollout.synchronize()
+        super(PAACLearner, self)._sync_device()
+
     def cleanup(self):
-        super(PAACLearner, self).cleanup()
+        super(PAACLearner, self).cleanup()       # save_vars(True) -> _sync_device() first
         if self.runners is not None:
             self.runners.stop()
             self.runners = None

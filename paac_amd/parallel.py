@@ -6,8 +6,78 @@ keeps the replicated weights identical.  The reference loss is a mean over the b
 (policy_v_network.py:49-53), so with equal shards the global gradient is (1/G) * sum_r grad_r; the 1/G is
 folded into paac_clip_rmsprop's grad_scale.  Nothing else is exchanged on the data path.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init_from_env(args=None):
+    """One process per GPU under `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment): picks this rank's GPU, rewrites args.device to '/gpu:<LOCAL_RANK>' and joins the process group --
+    backend "nccl" (= RCCL over xGMI) bound to that GPU -- BEFORE anything else touches the device.  A plain
+    `python -m paac_amd.train` (no WORLD_SIZE) stays a single process with no process group.  Returns the world size.
+
+    Knobs (tests and one-GPU rehearsals only): PAAC_DIST_BACKEND=gloo exchanges through the host instead of RCCL;
+    PAAC_DIST_SINGLE_DEVICE=1 puts every rank on GPU 0; PAAC_DIST_FORCE=1 joins a group even at WORLD_SIZE=1 (with
+    PAAC_FORCE_COLLECTIVES=1 the exchange then really issues its collectives, see `collectives_active`)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    forced = os.environ.get("PAAC_DIST_FORCE", "") == "1"
+    if world <= 1 and not forced:
+        return 1
+    if dist.is_initialized():
+        return dist.get_world_size()
+    local_rank = 0 if os.environ.get("PAAC_DIST_SINGLE_DEVICE", "") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("PAAC_DIST_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    if args is not None:
+        args.device = "/gpu:%d" % local_rank          # train.py:80 syntax; emulator_counts stays per GPU (weak scaling)
+    torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist.get_world_size()
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def collectives_active():
+    """True when the gradient exchange has to issue collectives: more than one rank, or a joined group with
+    PAAC_FORCE_COLLECTIVES=1 (the one-GPU RCCL smoke: a world of one still runs the stream-ordered all-reduce calls)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PAAC_FORCE_COLLECTIVES", "") == "1"
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def broadcast_(tensor, src=0):
+    """In-place broadcast from rank `src` (replicas start from rank 0's weights and optimizer slots)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(tensor, src=src)
+    return tensor
+
+
+def any_rank(flag, device):
+    """Logical OR of a host flag over all ranks (a stop request must be honoured by every rank at the same cycle, or
+    the ranks would disagree on the number of gradient exchanges and hang)."""
+    if world_size() <= 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+                     device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
 
 
 def world_size():
@@ -30,7 +100,7 @@ def shard_range(total_envs, r=None, world=None):
 
 def allreduce_sum_(flat_grad):
     """In-place sum all-reduce of the flat gradient (no-op for a single process)."""
-    if world_size() > 1:
+    if collectives_active():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
@@ -43,7 +113,7 @@ def side_group():
     Its collectives have their own communicator and stream, so a small all-reduce issued on it does not queue behind a
     large one still in flight on the default group."""
     global _side_group
-    if _side_group is None and world_size() > 1:
+    if _side_group is None and collectives_active():
         _side_group = dist.new_group(ranks=list(range(world_size())))
     return _side_group
 
@@ -52,7 +122,7 @@ def allreduce_sum_async(flat_grad, group=None):
     """Start an in-place sum all-reduce; returns the work handle (None for a single process).  With RCCL the
     collective runs on the process group's stream after the work already queued on the current stream, and
     `work.wait()` makes the current stream wait for it -- no host synchronisation."""
-    if world_size() > 1:
+    if collectives_active():
         return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 

@@ -13,7 +13,7 @@ import os
 import signal
 import sys
 
-from . import environment_creator, logger_utils
+from . import environment_creator, logger_utils, parallel
 from .paac import PAACLearner
 from .policy_v_network import NaturePolicyVNetwork, NIPSPolicyVNetwork
 
@@ -98,9 +98,16 @@ def get_network_and_environment_creator(args, random_seed=3):
 
 
 def _stop(learner, owner_pid, signum, frame):
+    """First signal: ask the training loop to stop at the next cycle boundary (it then runs cleanup() itself, with
+    nothing in flight on the GPU and, data parallel, every rank leaving at the same cycle).  Second signal: clean up
+    right here, as upstream does (train.py:38-49)."""
     if os.getpid() != owner_pid:          # forked emulator workers inherit the handler: only the trainer reacts
         return
-    logging.info('Signal %s detected, cleaning up.', signum)
+    if not learner.stop_requested:
+        logging.info('Signal %s detected, stopping at the next cycle boundary.', signum)
+        learner.stop_requested = True
+        return
+    logging.info('Signal %s detected again, cleaning up now.', signum)
     learner.cleanup()
     logging.info('Cleanup completed, shutting down...')
     sys.exit(0)
@@ -113,13 +120,18 @@ def setup_kill_signal_handler(learner):
 
 
 def main(args):
+    """train.py:24-35.  Under `python -m torch.distributed.run --nproc-per-node G -m paac_amd.train ...` every process
+    is one data-parallel rank: its GPU is '/gpu:<LOCAL_RANK>', `-ec` environments PER GPU (global_step advances by
+    G * ec per step), gradients are summed over RCCL once per update, rank 0 writes checkpoints / args / metrics."""
+    world = parallel.init_from_env(args)          # before anything touches a GPU
     logging.debug('Configuration: %s', args)
     network_creator, env_creator = get_network_and_environment_creator(args)
     learner = PAACLearner(network_creator, env_creator, args)
     setup_kill_signal_handler(learner)
-    logging.info('Starting training')
+    logging.info('Starting training (%d data-parallel rank%s)', world, '' if world == 1 else 's')
     learner.train()
     logging.info('Finished training')
+    parallel.shutdown()
 
 
 save_args = logger_utils.save_args      # logger_utils.py:15-20
@@ -128,5 +140,6 @@ save_args = logger_utils.save_args      # logger_utils.py:15-20
 if __name__ == '__main__':
     logging.basicConfig(stream=sys.stdout, level=logging.DEBUG)
     cli_args = get_arg_parser().parse_args()
-    save_args(cli_args, cli_args.debugging_folder)
+    if int(os.environ.get("RANK", "0")) == 0:
+        save_args(cli_args, cli_args.debugging_folder)
     main(cli_args)

@@ -81,6 +81,22 @@ def test_pools_match_oracle_restatement():
         assert np.array_equal(op.get_pooled_observations(), oo.get_pooled_observations())
 
 
+def test_oracle_luts_regenerate_from_pil():
+    """scipy.misc.imresize(img, (84, 84), interp='nearest') (atari_emulator.py:73) is PIL's NEAREST resize: the oracle's
+    row / column LUTs are what PIL does to a 210x160 image (columns 52 and 73 are where it leaves floor((x+.5)*s))."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import preprocess as opre
+    rows = np.repeat(np.arange(210, dtype=np.uint8)[:, None], 160, axis=1)
+    cols = np.repeat(np.arange(160, dtype=np.uint8)[None, :], 210, axis=0)
+    got_rows = np.asarray(Image.fromarray(rows).resize((84, 84), Image.NEAREST))[:, 0]
+    got_cols = np.asarray(Image.fromarray(cols).resize((84, 84), Image.NEAREST))[0, :]
+    assert np.array_equal(got_rows, opre.ROW_LUT) and np.array_equal(got_cols, opre.COL_LUT)
+    assert opre.COL_LUT[52] == 99 and opre.COL_LUT[73] == 139
+    img = np.random.RandomState(0).randint(0, 256, (2, 210, 160)).astype(np.uint8)
+    want = np.asarray(Image.fromarray(np.amax(img, axis=0)).resize((84, 84), Image.NEAREST))
+    assert np.array_equal(opre.max_resize(img), want)
+
+
 def test_synthetic_spec_luts_and_stats():
     from oracle import preprocess as opre
     from paac_amd import synthetic

@@ -41,7 +41,11 @@ def unflatten(ctx, flat):
                                       ("NIPS", 6, 40), ("NIPS", 4, 33), ("NIPS", 18, 160),
                                       ("NATURE", 4, 192),      # the device loop's training forward: N*(T+1) rows
                                       ("NATURE", 4, 1536),     # 256 envs x (5+1): size heuristics instead of the tuned table
-                                      ("NIPS", 6, 1280)])
+                                      ("NIPS", 6, 1280),
+                                      # BASELINE configs[3] per-GPU shard (Qbert A=6, 32 envs, t_max 5): acting / training rows
+                                      ("NATURE", 6, 32), ("NATURE", 6, 192),
+                                      # BASELINE configs[4] per-GPU shard (Seaquest A=18, 128 envs, t_max 20)
+                                      ("NATURE", 18, 128), ("NATURE", 18, 2688)])
 def test_forward_parity(arch, A, B):
     from paac_amd import hip_ops
     params, states, idx, y, adv = make_case(arch, A, B, seed=1)
@@ -73,7 +77,9 @@ def test_forward_parity(arch, A, B):
 @pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NATURE", 6, 40), ("NATURE", 18, 9), ("NIPS", 6, 40),
                                       ("NIPS", 4, 160), ("NATURE", 4, 320),
                                       ("NATURE", 4, 1280),     # 256 envs x t_max 5 (BASELINE configs[2]): heuristics
-                                      ("NIPS", 6, 640)])
+                                      ("NIPS", 6, 640),
+                                      ("NATURE", 6, 160),      # configs[3] shard: 32 envs x t_max 5, Qbert action set
+                                      ("NATURE", 18, 2560)])   # configs[4] shard: 128 envs x t_max 20, Seaquest action set
 def test_backward_parity(arch, A, B):
     from paac_amd import hip_ops
     params, states, idx, y, adv = make_case(arch, A, B, seed=2)

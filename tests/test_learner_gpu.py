@@ -127,6 +127,47 @@ def test_device_loop_matches_host_loop(raw_frames, use_graph):
     ro.close()
 
 
+@pytest.mark.parametrize("game,N,T,cycles", [
+    ("breakout", 32, 5, 3),      # BASELINE configs[1] (the headline): fused numpy-parity sampler + env-step launch
+    ("qbert", 32, 5, 2),         # BASELINE configs[3] per-GPU shard (A=6)
+    ("seaquest", 128, 20, 1),    # BASELINE configs[4] per-GPU shard (A=18): N*(A-1) draws exceed the fused sampler's
+])                               # table -> paac_forward + paac_sample_mt (global scratch) + paac_synth_step
+def test_device_loop_matches_oracle(game, N, T, cycles):
+    """The device-resident cycle (hipGraph replay, numpy-parity sampler) against the CPU restatement of paac.py:99-165
+    on the same synthetic environments and np.random stream: observations and actions bit for bit, values / returns /
+    weights within the float tolerance."""
+    from paac_amd import hip_ops
+    from paac_amd.paac import DeviceRollout
+    args = make_args(game=game, arch="NATURE", emulator_counts=N, emulator_workers=0, max_local_steps=T,
+                     max_global_steps=1 << 40, synthetic_terminal_p=0.05, sampler="numpy", test_seed=11)
+    learner, params, env_creator = build_learner(args)
+    A = args.num_actions
+    assert (N * (A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS) == (game != "seaquest")
+    np.random.seed(args.test_seed)
+    learner.global_step = learner.init_network()
+    ro = DeviceRollout(learner, env_creator.device_env_spec, sampler="numpy", use_graph=True)
+    want = oracle_cycles(args, params, env_creator, cycles, "NATURE")
+    for c in range(cycles):
+        ro.run_cycle()
+        ro.synchronize()
+        assert np.array_equal(ro.actions.view(-1).cpu().numpy(), np.argmax(want[c]["actions"], axis=1)), "cycle %d" % c
+        assert np.array_equal(ro.rollout_states().cpu().numpy(), want[c]["states"]), "cycle %d" % c
+        assert np.abs(ro.values.cpu().numpy() - want[c]["values"]).max() < 1e-4
+        assert np.abs(ro.y.cpu().numpy() - want[c]["y"]).max() < 2e-4
+        assert np.abs(ro.adv.cpu().numpy() - want[c]["adv"]).max() < 3e-4
+        assert float(learner.lr_dev.item()) == float(np.float32(want[c]["lr"]))
+        assert int(ro.global_step_dev.item()) == want[c]["global_step"]
+    got = learner.network.get_parameters()
+    for k, v in want[-1]["params"].items():
+        assert np.abs(got[k] - v).max() < 2e-4, k
+    rs = np.random.RandomState(args.test_seed)          # stream position after the last cycle
+    for c in range(cycles):
+        for t in range(T):
+            osamp.sample_mt_restated(want[c]["pis"][t], rs)
+    assert hip_ops.mt_state_to_numpy(ro.mt_state)[2] == rs.get_state()[2]
+    ro.close()
+
+
 def test_choose_next_actions_dropin():
     """Static helper used by the reference's test.py:77 -- same signature, numpy in/out, global np.random stream."""
     from paac_amd.paac import PAACLearner

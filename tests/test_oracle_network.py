@@ -79,18 +79,3 @@ def test_clip_and_rmsprop_semantics():
     ms_e = 1.0 + (4.0 - 1.0) * 0.01
     assert abs(ms["w"][0] - ms_e) < 1e-6
     assert abs(p["w"][0] - (1.0 - 0.1 * 2.0 / np.sqrt(ms_e + 0.1))) < 1e-6
-
-
-def test_meta_constants_present():
-    """Constants the oracle hard-codes are the ones frozen in the reference's NIPS graph .meta
-    (read as bytes; nothing is executed).  Skipped where /root/reference is absent (GPU box)."""
-    import os
-    meta = "/root/reference/pretrained/breakout/checkpoints/-80000000.meta"
-    if not os.path.exists(meta):
-        pytest.skip("reference not mounted")
-    blob = open(meta, "rb").read()
-    for name in [b"clip_by_global_norm", b"OptimizerVariables", b"conv1_weights", b"fc3_weights",
-                 b"actor_output_weights", b"critic_output_biases", b"ApplyRMSProp"]:
-        assert name in blob
-    assert np.float32(1.0 / 255.0).tobytes() in blob               # input scale const
-    assert np.float32(1e-30).tobytes() in blob                      # log epsilon
