@@ -11,13 +11,21 @@ RMSProp, on synthetic 84x84x4 uint8 frames generated on the device; value = env-
 slowest rank's wall time (weak scaling: 32 envs per GPU).  Workload at N=1 = BASELINE configs[1]
 (Breakout action set, Nature net, 32 envs, t_max=5).
 
+The timed region is repeated: `--windows` (default 5) consecutive windows of exactly K steps, each bracketed by
+barrier + synchronize on both sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN window's
+(a 20-step window is 7 ms: one window alone is at the mercy of a clock ramp), all windows are listed in `windows_ms`.
+
 Extra objects on the JSON line:
   roofline     -- the kernel family with the largest share of the cycle, timed with HIP events attached to the
                   kernel dispatches (hipExtLaunchKernelGGL start/stop events on the launch stream) in a second,
                   eager (graph-free) pass over the same K steps; achieved = algorithmic FLOPs (or bytes) per
                   launch / average launch duration; traffic = PMC bytes per launch from profiles/ (separate passes).
   cpu_baseline -- oracle/cpu_learner.py (torch-CPU port of the reference loop; the reference's TF path cannot
-                  run here) on a bounded sample, rank 0, N=1 only.
+                  run here) on a bounded sample, rank 0, N=1 only: thread count calibrated once, then the median of
+                  three equal windows.
+  host_plugin_loop (only with --host-envs) -- the same workload with the environments as host BaseEnvironment
+                  plugins (PAACLearner._train_host: per step 32 x 28 KB observations H2D + the action indices D2H,
+                  eager launches): the PCIe-inclusive rate a real emulator would see.  Reported beside `value`, never as it.
 """
 import argparse
 import json
@@ -35,7 +43,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16; conv1 spends 3 exact bf16 products
 PEAK_HBM_GBS = 8000.0
 
 
-def family_work(name, batch, arch, A, P):
+def family_work(name, batch, arch, A, P, raw=False):
     """Algorithmic work of one launch of a kernel family: (kind, amount) with kind 'flop' or 'byte'."""
     if arch == "NATURE":
         C1, C2, C3, H, FLAT = 32, 64, 64, 512, 3136
@@ -56,7 +64,41 @@ def family_work(name, batch, arch, A, P):
         return "byte", 4.0 * batch * H * 2 + 4.0 * H * (A + 1)
     if name == "heads_bwd":
         return "byte", 4.0 * batch * H * 3 + 4.0 * H * (A + 1) * 2
+    # kernels around the network: batch = environments per launch (nstep_returns: N*T elements)
+    OBS, RAW = 28224.0, 2 * 33600.0
+    if name in ("env_step", "sample_env_step"):      # read the stacks, write the shifted stacks (+ the sampler's [N,A] probs)
+        if raw and name == "env_step":                # path B: the step WRITES the two raw 210x160 screens
+            return "byte", batch * (RAW + 24.0)
+        return "byte", batch * (2 * OBS + (4.0 * A if name == "sample_env_step" else 0.0) + 24.0)
+    if name == "preprocess_stack":                    # two raw screens in, stack in, stack out
+        return "byte", batch * (RAW + 2 * OBS)
+    if name in ("sample_mt", "sample_philox"):
+        return "byte", batch * (4.0 * A + 4.0) + (2496.0 * 2 if name == "sample_mt" else 0.0)
+    if name == "nstep_returns":                       # rewards, masks, values in; y, adv out
+        return "byte", batch * 20.0
     return "byte", 0.0
+
+
+def time_host_plugin_loop(a, train, PAACLearner, np, cycles=60, warm=10):
+    """PAACLearner._train_host on SyntheticEnvironment host plugins, same workload: env-steps/s over the cycles after
+    `warm` (per step: N x 28 KB observations H2D, one sync'ing D2H of the action indices, eager kernel launches)."""
+    args = train.get_arg_parser().parse_args([])
+    args.game, args.arch = a.game, a.arch
+    args.emulator_counts, args.max_local_steps, args.emulator_workers = a.envs, a.tmax, 0
+    args.host_environments, args.metrics = True, False
+    args.max_global_steps = cycles * a.envs * a.tmax
+    args.debugging_folder = tempfile.mkdtemp(prefix="paac_bench_host_")
+    stamps = []
+    args.cycle_callback = lambda step: stamps.append(time.perf_counter())
+    network_creator, env_creator = train.get_network_and_environment_creator(args)
+    learner = PAACLearner(network_creator, env_creator, args)
+    learner.network.init = lambda folder, saver, session: (learner.network.initialize(np.random.RandomState(0)), 0)[1]
+    np.random.seed(42)
+    learner.train()
+    dt = stamps[-1] - stamps[warm - 1]
+    return dict(value=round((cycles - warm) * a.envs * a.tmax / dt, 1), unit="env-steps/s", cycles=cycles - warm,
+                note="host BaseEnvironment plugins stepped in-process (synthetic, numpy), observations H2D and actions "
+                     "D2H every step, eager launches; PCIe-inclusive, not `value`")
 
 
 def main():
@@ -74,6 +116,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--windows", type=int, default=5, help="consecutive K-step windows; the median one is reported")
+    ap.add_argument("--host-envs", action="store_true",
+                    help="also time the host-plugin loop (PCIe-inclusive) on the same workload; reported beside value")
     a = ap.parse_args()
 
     import numpy as np
@@ -133,16 +178,20 @@ def main():
             ro.capture()                # recording the graphs executes nothing: kept out of the timed region even at W = 0
     ro.run_cycles(a.warmup)
     ro.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    ro.run_cycles(a.steps)          # exactly K cycles (graph replay batches them 4 per launch where it can)
-    ro.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    windows = []
+    for _ in range(max(1, a.windows)):
+        barrier()
+        t0 = time.perf_counter()
+        ro.run_cycles(a.steps)          # exactly K cycles (graph replay batches them 4 per launch where it can)
+        ro.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        windows.append(dt)
+    elapsed = sorted(windows)[len(windows) // 2]          # the median window
     value = world * N * T * a.steps / elapsed
     finite = bool(torch.isfinite(learner.network.params).all().item())
 
@@ -179,12 +228,12 @@ def main():
         arch = "NIPS" if a.arch == "NIPS" else "NATURE"
         kernels = []
         for (name, batch), (ms, cnt) in per.items():
-            kind, amount = family_work(name, batch, arch, A, P)
+            kind, amount = family_work(name, batch, arch, A, P, raw=a.raw_frames)
             avg_us = 1000.0 * ms / cnt
             ach = amount / (avg_us * 1e-6) if avg_us > 0 else 0.0
             kernels.append(dict(kernel=name, batch=batch, launches_per_step=cnt / a.steps, avg_us=round(avg_us, 3),
                                 us_per_step=round(1000.0 * ms / a.steps, 2),
-                                achieved=round(ach / 1e12, 3) if kind == "flop" else round(ach / 1e9, 1),
+                                achieved=(round(ach / 1e12, 3) if kind == "flop" else round(ach / 1e9, 1)) if amount > 0 else None,
                                 unit="TFLOP/s" if kind == "flop" else "GB/s"))
         kernels.sort(key=lambda k: -k["us_per_step"])
         dom = kernels[0]
@@ -227,13 +276,20 @@ def main():
         res = cpu_learner.run(envs, a.arch, A, T, params, min_seconds=a.cpu_seconds)
         cpu_baseline = dict(value=round(res["steps_per_s"], 1), unit="env-steps/s", cores=res["cores"], kind="port",
                             sample="%d cycles of the same workload (%d envs x t_max %d, %s net) in %.1f s, torch-CPU fp32 port "
-                                   "of the reference loop" % (res["cycles"], N, T, a.arch, res["seconds"]))
+                                   "of the reference loop; median of %d windows (%s env-steps/s), %d threads fixed after calibration"
+                                   % (res["cycles"], N, T, a.arch, res["seconds"], res["windows"],
+                                      "/".join("%.0f" % r for r in res["window_rates"]), res["cores"]))
+
+    host_loop = None
+    if rank == 0 and world == 1 and a.host_envs:
+        host_loop = time_host_plugin_loop(a, train, PAACLearner, np)
 
     if rank == 0:
         out = {
             "metric": "global env-steps/sec at 32 envs, t_max=5, Nature net; 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1000.0 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000.0 * elapsed / a.steps, 4),
+            "windows_ms": [round(1000.0 * w, 3) for w in windows], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s action set (A=%d), %s net, %d envs per GPU x %d GPU, t_max=%d, %s, sampler=%s, %s"
                                    % (a.game, A, a.arch, N, world, T,
@@ -248,7 +304,7 @@ def main():
                                      "dropped",
                        "parallelism": "env-sharded dp%d, RCCL sum all-reduce of the flat gradient per update (fc/heads part overlapped with the conv backward)" % world},
             "finite_params": finite,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "host_plugin_loop": host_loop, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     ro.close()

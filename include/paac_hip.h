@@ -120,6 +120,14 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
                       const float* lr_dev, float decay, float momentum, float eps, float clip_norm,
                       int clip_mode, float grad_scale, float* gnorm_out, paac_stream_t stream);
 
+/* The reference's gradient summaries (actor_learner.py:85-87 -> logger_utils.py:23-33: mean, stddev, max, min of the
+ * flat raw gradient and of the flat clipped gradient, plus global_norm): the reductions ride along the norm pass of
+ * the LAST paac_clip_rmsprop on this ctx (no extra pass over the gradient); this call only folds its per-block
+ * partials.  stats_out: device float[8] = {sum, sum of squares, max, min, number of exact zeros, 0, 0, 0} of the raw
+ * flat gradient (g * grad_scale) over the reference's P elements (alignment pads excluded).  The clipped gradient is
+ * the raw one times clip_norm*min(1/gn, 1/clip_norm), so its statistics follow.  Call at the logging cadence. */
+int paac_grad_stats(paac_ctx* ctx, float* stats_out, paac_stream_t stream);
+
 /* actor_learner.py:119-123 + paac.py:127: *global_step += increment; *lr_out = f32(lr0 - step*lr0/anneal)
  * (0 beyond anneal); evaluated in fp64 like the reference's Python float. */
 int paac_lr_step(int64_t* global_step_dev, int64_t increment, double initial_lr, int64_t lr_annealing_steps,
@@ -214,8 +222,9 @@ int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);
  * launch is bracketed by hipEvents on the launch stream (do not enable inside graph capture).
  * paac_prof_read synchronises the recorded events and returns, per launch, its kernel family, the batch it
  * processed and its duration in ms (up to max_events; the internal table holds 8192 launches); returns the
- * number of records written and clears the table. */
-#define PAAC_PROF_FAMILIES 16
+ * number of records written and clears the table.  The entry points that take no ctx (environment step, samplers,
+ * n-step returns, preprocessing) are recorded in the table of the ctx profiling was last enabled on. */
+#define PAAC_PROF_FAMILIES 22
 int paac_prof_enable(paac_ctx* ctx, int on);
 int paac_prof_read(paac_ctx* ctx, int32_t* family_out, int32_t* batch_out, float* ms_out, int max_events);
 const char* paac_prof_name(int family);

@@ -66,8 +66,8 @@ class TorchNet(object):
 
 
 def run(envs, arch, num_actions, T, params, min_seconds=10.0, warmup_cycles=2, seed=42, gamma=0.99,
-        initial_lr=0.0224, lr_annealing_steps=80000000):
-    """Time the port.  Returns dict(steps_per_s, cycles, seconds, cores)."""
+        initial_lr=0.0224, lr_annealing_steps=80000000, windows=3):
+    """Time the port.  Returns dict(steps_per_s = median over `windows` windows, cycles, seconds, cores, ...)."""
     net = TorchNet(arch, num_actions, params)
     rs = np.random.RandomState(seed)
     def sample(pi):
@@ -87,25 +87,33 @@ def run(envs, arch, num_actions, T, params, min_seconds=10.0, warmup_cycles=2, s
 
     for _ in range(warmup_cycles):
         one_cycle()
-    # pick the intra-op thread count that runs this small-batch loop fastest (all cores is rarely it)
+    # pick the intra-op thread count that runs this small-batch loop fastest (all cores is rarely it): 4 timed cycles per
+    # candidate, then the count stays fixed for every timed window
     all_cores = torch.get_num_threads()
     best = (None, float("inf"))
     for nt in sorted({all_cores, max(1, all_cores // 2), max(1, all_cores // 4), min(all_cores, 16), min(all_cores, 8)}):
         torch.set_num_threads(nt)
         one_cycle()
         t = time.time()
-        one_cycle()
-        one_cycle()
+        for _ in range(4):
+            one_cycle()
         dt = time.time() - t
         if dt < best[1]:
             best = (nt, dt)
     torch.set_num_threads(best[0])
-    t0 = time.time()
-    cycles = 0
-    while True:
-        one_cycle()
-        cycles += 1
-        dt = time.time() - t0
-        if dt >= min_seconds:
-            break
-    return dict(steps_per_s=cycles * N * T / dt, cycles=cycles, seconds=dt, cores=torch.get_num_threads())
+    # `windows` equal windows; the reported rate is the median window's
+    rates, total_cycles, t_all = [], 0, time.time()
+    for _ in range(windows):
+        t0 = time.time()
+        cycles = 0
+        while True:
+            one_cycle()
+            cycles += 1
+            dt = time.time() - t0
+            if dt >= min_seconds / windows:
+                break
+        rates.append(cycles * N * T / dt)
+        total_cycles += cycles
+    rates.sort()
+    return dict(steps_per_s=rates[len(rates) // 2], cycles=total_cycles, seconds=time.time() - t_all,
+                cores=torch.get_num_threads(), windows=windows, window_rates=rates)

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, hip_ops, parallel
 from .networks import Placeholder
-from .session import Saver, Session
+from .session import Saver, Session, checkpoint_key, tensor_of_key
 
 CHECKPOINT_INTERVAL = 1000000      # actor_learner.py:8
 
@@ -77,31 +77,33 @@ class ActorLearner(object):
                                    device_index=dev.index or 0)
         self.session = Session(self.network, self.ctx, learner=self)
 
-        scope = self.network.name
-        self.network_saver = Saver(lambda: {"%s/%s" % (scope, k): v for k, v in self.network.get_parameters().items()},
-                                   lambda d: self.network.set_parameters({k.split("/", 1)[1]: v for k, v in d.items()}))
+        self.network_saver = self.network.make_saver()
         self.optimizer_saver = Saver(self._get_optimizer_arrays, self._set_optimizer_arrays, max_to_keep=1)
 
-    # -- optimizer slots in the reference's naming ---------------------------------------------------
+    # -- optimizer slots under the reference's names ('<var>/OptimizerVariables', '<var>/OptimizerVariables_1') ----
     def _get_optimizer_arrays(self):
         scope = self.network.name
         out = {}
-        for k, v in self.network.get_parameters(self.rms).items():
-            out["%s/%s/OptimizerVariables" % (scope, k)] = v
-        for k, v in self.network.get_parameters(self.mom).items():
-            out["%s/%s/OptimizerVariables_1" % (scope, k)] = v
+        for slot, flat in (("OptimizerVariables", self.rms), ("OptimizerVariables_1", self.mom)):
+            for k, v in self.network.get_parameters(flat).items():
+                out[checkpoint_key(scope, k, slot)] = v
         return out
 
     def _set_optimizer_arrays(self, d):
         lay = self.network.layout
-        rms = np.ones(lay["total"], dtype=np.float32)
-        mom = np.zeros(lay["total"], dtype=np.float32)
-        for t in lay["tensors"]:
-            for suffix, dst in (("OptimizerVariables", rms), ("OptimizerVariables_1", mom)):
-                key = "%s/%s/%s" % (self.network.name, t["name"], suffix)
-                dst[t["offset"]:t["offset"] + t["size"]] = np.asarray(d[key], dtype=np.float32).reshape(-1)
-        self.rms.copy_(torch.from_numpy(rms))
-        self.mom.copy_(torch.from_numpy(mom))
+        host = {"OptimizerVariables": np.ones(lay["total"], dtype=np.float32),
+                "OptimizerVariables_1": np.zeros(lay["total"], dtype=np.float32)}
+        where = {t["name"]: t for t in lay["tensors"]}
+        seen = set()
+        for key, value in d.items():
+            name, slot = tensor_of_key(key)
+            t = where[name]
+            host[slot][t["offset"]:t["offset"] + t["size"]] = np.asarray(value, dtype=np.float32).reshape(-1)
+            seen.add((name, slot))
+        if len(seen) != 2 * len(where):
+            raise KeyError("optimizer checkpoint holds %d of %d slot tensors" % (len(seen), 2 * len(where)))
+        self.rms.copy_(torch.from_numpy(host["OptimizerVariables"]))
+        self.mom.copy_(torch.from_numpy(host["OptimizerVariables_1"]))
 
     # -- one optimizer step from a reference-style feed dict (Session.run([train_step, ...], feed)) ----
     def _train_step_from_feed(self, feed_dict):

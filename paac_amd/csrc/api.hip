@@ -10,6 +10,7 @@ namespace paac {
 
 static thread_local char g_err[512] = "";
 thread_local ProfEvents g_prof = {nullptr, nullptr};
+paac_ctx* g_prof_ctx = nullptr;
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -44,7 +45,8 @@ int fc_splits_max();
 
 static const char* kFamilyNames[PAAC_PROF_FAMILIES] = {
     "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "heads_fwd", "heads_bwd", "fc_wgrad", "fc_dgrad",
-    "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "misc"};
+    "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "misc",
+    "env_step", "sample_env_step", "sample_mt", "sample_philox", "nstep_returns", "preprocess_stack"};
 
 }  // namespace paac
 
@@ -354,6 +356,8 @@ int paac_prof_enable(paac_ctx* ctx, int on) {
     }
   }
   ctx->prof_on = on ? 1 : 0;
+  if (on) g_prof_ctx = ctx;
+  else if (g_prof_ctx == ctx) g_prof_ctx = nullptr;
   return 0;
 }
 

@@ -48,9 +48,11 @@ ArchSpec arch_spec(int arch);
 enum Family {
   F_CONV1_FWD = 0, F_CONV2_FWD, F_CONV3_FWD, F_FC_FWD, F_HEADS_FWD,
   F_HEADS_BWD, F_FC_WGRAD, F_FC_DGRAD, F_CONV3_WGRAD, F_CONV3_DGRAD, F_CONV2_WGRAD, F_CONV2_DGRAD, F_CONV1_WGRAD,
-  F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_MISC
+  F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_MISC,
+  // the kernels around the network (entry points without a ctx: timed through the ctx profiling was enabled on)
+  F_ENV_STEP, F_SAMPLE_ENV_STEP, F_SAMPLE_MT, F_SAMPLE_PHILOX, F_NSTEP_RETURNS, F_PREPROCESS_STACK
 };
-static_assert(F_MISC + 1 == PAAC_PROF_FAMILIES, "family count");
+static_assert(F_PREPROCESS_STACK + 1 == PAAC_PROF_FAMILIES, "family count");
 
 }  // namespace paac
 
@@ -115,6 +117,7 @@ struct ProfEvents {
   hipEvent_t start, stop;
 };
 extern thread_local ProfEvents g_prof;
+extern paac_ctx* g_prof_ctx;   // the ctx paac_prof_enable(ctx, 1) was last called on (nullptr: none)
 
 struct ProfScope {
   paac_ctx* ctx;

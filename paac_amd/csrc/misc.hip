@@ -591,32 +591,98 @@ __global__ void fill_f32_kernel(float* p, float v, int n) {
 // Global-norm clip + TF RMSProp over the flat parameter buffer (actor_learner.py:31-34,56-59,70).
 constexpr int NORM_BLOCKS = 256;
 
+// partials layout (NORM_BLOCKS floats each): [0] sum of squares (what the clip needs), then what the reference's gradient
+// summaries need (logger_utils.py:23-33 over the flat gradient, actor_learner.py:85-87): [1] sum, [2] max and [3] min over
+// the NONZERO elements, [4] number of exact zeros.  The flat buffer's alignment pads are zeros the reference's flat
+// gradient does not contain; the reader (grad_stats_kernel) knows how many pads there are, so zeros count for max / min
+// only when more zeros were seen than there are pads.  A few VALU ops per element on a latency-bound kernel.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float scale,
                                                     float* __restrict__ partials) {
   // latency-bound (a few float4 per thread): every load of a pass is issued before the first one is consumed
   constexpr int U = 8;
   constexpr long STRIDE = (long)NORM_BLOCKS * 256;
-  float acc = 0.f;
+  float acc = 0.f, sum = 0.f, mx = -INFINITY, mn = INFINITY, zeros = 0.f;
   const float4* g4 = reinterpret_cast<const float4*>(g);
   for (long i0 = blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * STRIDE) {
     float4 v[U];
+    bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long i = i0 + u * STRIDE;
-      v[u] = (i < n4) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      live[u] = i < n4;
+      v[u] = live[u] ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float x = v[u].x * scale, y = v[u].y * scale, z = v[u].z * scale, w = v[u].w * scale;
       acc += (x * x + y * y) + (z * z + w * w);
+      if (live[u]) {
+        sum += (x + y) + (z + w);
+        const float e[4] = {x, y, z, w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool nz = e[c] != 0.f;
+          mx = fmaxf(mx, nz ? e[c] : -INFINITY);
+          mn = fminf(mn, nz ? e[c] : INFINITY);
+          zeros += nz ? 0.f : 1.f;
+        }
+      }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_down(acc, off, 64);
+    sum += __shfl_down(sum, off, 64);
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+    zeros += __shfl_down(zeros, off, 64);
+  }
+  __shared__ float red[5][4];
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    red[0][w] = acc; red[1][w] = sum; red[2][w] = mx; red[3][w] = mn; red[4][w] = zeros;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[NORM_BLOCKS + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    partials[2 * NORM_BLOCKS + blockIdx.x] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    partials[3 * NORM_BLOCKS + blockIdx.x] = fminf(fminf(red[3][0], red[3][1]), fminf(red[3][2], red[3][3]));
+    partials[4 * NORM_BLOCKS + blockIdx.x] = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+  }
+}
+
+// One workgroup: the partials of the last sumsq_kernel -> out[8] = {sum, sum of squares, max, min, exact zeros among the
+// real (unpadded) elements, 0, 0, 0}.  Launched by the host at the progress-record cadence only.
+__global__ __launch_bounds__(NORM_BLOCKS) void grad_stats_kernel(const float* __restrict__ partials, float pads,
+                                                                 float* __restrict__ out) {
+  const int t = threadIdx.x;
+  float ss = partials[t], sum = partials[NORM_BLOCKS + t], mx = partials[2 * NORM_BLOCKS + t],
+        mn = partials[3 * NORM_BLOCKS + t], zeros = partials[4 * NORM_BLOCKS + t];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ss += __shfl_down(ss, off, 64);
+    sum += __shfl_down(sum, off, 64);
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+    zeros += __shfl_down(zeros, off, 64);
+  }
+  __shared__ float red[5][NORM_BLOCKS / 64];
+  if ((t & 63) == 0) {
+    const int w = t >> 6;
+    red[0][w] = ss; red[1][w] = sum; red[2][w] = mx; red[3][w] = mn; red[4][w] = zeros;
+  }
+  __syncthreads();
+  if (t == 0) {
+    constexpr int W = NORM_BLOCKS / 64;
+    float a = 0.f, b = 0.f, c = -INFINITY, d = INFINITY, z = 0.f;
+    for (int w = 0; w < W; ++w) {
+      a += red[0][w]; b += red[1][w]; c = fmaxf(c, red[2][w]); d = fminf(d, red[3][w]); z += red[4][w];
+    }
+    const float real_zeros = z - pads;
+    if (real_zeros > 0.f) { c = fmaxf(c, 0.f); d = fminf(d, 0.f); }
+    out[0] = b; out[1] = a; out[2] = c; out[3] = d; out[4] = real_zeros; out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
+  }
 }
 
 constexpr int RMS_U = 4;   // float4 per thread and array in rmsprop_kernel
@@ -700,8 +766,9 @@ int paac_nstep_returns(const float* v_boot, const float* rewards, const float* m
   PAAC_REQUIRE(T > 0 && N > 0, "paac_nstep_returns: T=%d N=%d", T, N);
   CycleTick ct;
   memset(&ct, 0, sizeof(ct));
-  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(128), 0, (hipStream_t)stream, v_boot, rewards, masks,
-                     values, T, N, gamma, y, adv, ct);
+  ProfScope ps(g_prof_ctx, F_NSTEP_RETURNS, N * T, (hipStream_t)stream);
+  launch_k(nstep_returns_kernel, dim3((N + 63) / 64), dim3(128), (hipStream_t)stream, PROF_WHOLE, v_boot, rewards, masks,
+           values, T, N, gamma, y, adv, ct);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -715,8 +782,9 @@ int paac_nstep_returns_tick(const float* v_boot, const float* rewards, const flo
   CycleTick ct;
   ct.global_step = global_step_dev; ct.step_inc = increment; ct.lr0 = initial_lr; ct.anneal = lr_annealing_steps;
   ct.lr_out = lr_out_dev; ct.tick = tick_dev; ct.tick_inc = tick_inc;
-  hipLaunchKernelGGL(nstep_returns_kernel, dim3((N + 63) / 64), dim3(128), 0, (hipStream_t)stream, v_boot, rewards, masks,
-                     values, T, N, gamma, y, adv, ct);
+  ProfScope ps(g_prof_ctx, F_NSTEP_RETURNS, N * T, (hipStream_t)stream);
+  launch_k(nstep_returns_kernel, dim3((N + 63) / 64), dim3(128), (hipStream_t)stream, PROF_WHOLE, v_boot, rewards, masks,
+           values, T, N, gamma, y, adv, ct);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -745,8 +813,9 @@ int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream) {
 int paac_sample_philox(const float* probs, int N, int A, uint64_t seed, const uint64_t* step_base_dev,
                        uint64_t step_offset, uint32_t env_offset, int32_t* actions, paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_philox: N=%d A=%d", N, A);
-  hipLaunchKernelGGL(sample_philox_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, probs, N, A, seed,
-                     step_base_dev, step_offset, env_offset, actions);
+  ProfScope ps(g_prof_ctx, F_SAMPLE_PHILOX, N, (hipStream_t)stream);
+  launch_k(sample_philox_kernel, dim3((N + 63) / 64), dim3(64), (hipStream_t)stream, PROF_WHOLE, probs, N, A, seed,
+           step_base_dev, step_offset, env_offset, actions);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -765,12 +834,13 @@ int paac_sample_mt(const float* probs, int N, int A, uint32_t* mt_state, void* s
   double* pj = (double*)scratch;
   double* u = pj + D;
   uint32_t* blocks = (uint32_t*)(u + D);
+  ProfScope ps(g_prof_ctx, F_SAMPLE_MT, N, (hipStream_t)stream);
   if (D <= MT_LDS_D)
-    hipLaunchKernelGGL((sample_mt_kernel<true>), dim3(1), dim3(256), 0, (hipStream_t)stream, probs, N, A, mt_state, pj,
-                       u, blocks, actions);
+    launch_k(sample_mt_kernel<true>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
+             blocks, actions);
   else
-    hipLaunchKernelGGL((sample_mt_kernel<false>), dim3(1), dim3(256), 0, (hipStream_t)stream, probs, N, A, mt_state, pj,
-                       u, blocks, actions);
+    launch_k(sample_mt_kernel<false>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
+             blocks, actions);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -779,14 +849,15 @@ int paac_preprocess_stack(const uint8_t* raw, int is_rgb, int N, const uint8_t* 
                           const uint8_t* push_mask, const uint8_t* reset_mask, paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && raw && stack_in && stack_out, "paac_preprocess_stack: bad arguments");
   dim3 grid(N, PRE_BANDS);
+  ProfScope ps(g_prof_ctx, F_PREPROCESS_STACK, N, (hipStream_t)stream);
   if (is_rgb)
-    hipLaunchKernelGGL((preprocess_stack_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, raw, N,
-                       (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)nullptr, push_mask, reset_mask,
-                       (const float*)nullptr);
+    launch_k(preprocess_stack_kernel<true>, grid, dim3(256), (hipStream_t)stream, PROF_WHOLE, raw, N,
+             (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)nullptr, push_mask, reset_mask,
+             (const float*)nullptr);
   else
-    hipLaunchKernelGGL((preprocess_stack_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, raw, N,
-                       (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)nullptr, push_mask, reset_mask,
-                       (const float*)nullptr);
+    launch_k(preprocess_stack_kernel<false>, grid, dim3(256), (hipStream_t)stream, PROF_WHOLE, raw, N,
+             (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)nullptr, push_mask, reset_mask,
+             (const float*)nullptr);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -823,17 +894,21 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
                "paac_synth_step: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (!raw_scratch) {
-    hipLaunchKernelGGL(synth_step_a_kernel, dim3(N, PRE_BANDS), dim3(256), 0, s, seed, env_offset, N, actions,
-                       terminal_threshold, step_base_dev, step_offset, 0, (const uint32_t*)stack_in,
-                       (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len,
-                       (FinishedRing*)finished);
+    ProfScope ps(g_prof_ctx, F_ENV_STEP, N, s);
+    launch_k(synth_step_a_kernel, dim3(N, PRE_BANDS), dim3(256), s, PROF_WHOLE, seed, env_offset, N, actions,
+             terminal_threshold, step_base_dev, step_offset, 0, (const uint32_t*)stack_in, (uint32_t*)stack_out,
+             (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
   } else {
-    hipLaunchKernelGGL(synth_raw_kernel, dim3(N, 8), dim3(256), 0, s, seed, env_offset, N, actions, terminal_threshold,
-                       step_base_dev, step_offset, 0, (uint32_t*)raw_scratch, rewards_out, masks_out, ep_reward, ep_len,
-                       (FinishedRing*)finished);
-    hipLaunchKernelGGL((preprocess_stack_kernel<false>), dim3(N, PRE_BANDS), dim3(256), 0, s, raw_scratch, N,
-                       (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)stack_out2, (const uint8_t*)nullptr,
-                       (const uint8_t*)nullptr, (const float*)masks_out);
+    {
+      ProfScope ps(g_prof_ctx, F_ENV_STEP, N, s);
+      launch_k(synth_raw_kernel, dim3(N, 8), dim3(256), s, PROF_WHOLE, seed, env_offset, N, actions, terminal_threshold,
+               step_base_dev, step_offset, 0, (uint32_t*)raw_scratch, rewards_out, masks_out, ep_reward, ep_len,
+               (FinishedRing*)finished);
+    }
+    ProfScope ps(g_prof_ctx, F_PREPROCESS_STACK, N, s);
+    launch_k(preprocess_stack_kernel<false>, dim3(N, PRE_BANDS), dim3(256), s, PROF_WHOLE, raw_scratch, N,
+             (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)stack_out2, (const uint8_t*)nullptr,
+             (const uint8_t*)nullptr, (const float*)masks_out);
   }
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -849,10 +924,10 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
                "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D);
   PAAC_REQUIRE(probs && mt_state && actions && stack_in && stack_out && rewards_out && masks_out && ep_reward && ep_len,
                "paac_sample_mt_synth_step: null argument");
-  hipLaunchKernelGGL(synth_step_a_mt_kernel, dim3(1 + N * PRE_BANDS), dim3(256), 0, (hipStream_t)stream, probs, A,
-                     mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset,
-                     (const uint32_t*)stack_in, (uint32_t*)stack_out, rewards_out, masks_out, ep_reward, ep_len,
-                     (FinishedRing*)finished);
+  ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, (hipStream_t)stream);
+  launch_k(synth_step_a_mt_kernel, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
+           actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
+           (uint32_t*)stack_out, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -874,6 +949,15 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   else
     launch_k(rmsprop_kernel<false>, dim3((n4 + 256 * RMS_U - 1) / (256 * RMS_U)), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
              decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_grad_stats(paac_ctx* ctx, float* stats_out, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && stats_out, "paac_grad_stats: null argument");
+  const float pads = (float)(ctx->layout.total - ctx->layout.total_unpadded);
+  hipLaunchKernelGGL(grad_stats_kernel, dim3(1), dim3(NORM_BLOCKS), 0, (hipStream_t)stream, (const float*)ctx->partials,
+                     pads, stats_out);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -158,6 +158,23 @@ class Context(object):
                                               _ptr(gnorm_out, torch.float32, 1, "gnorm_out", True), _stream()),
                    "paac_clip_rmsprop")
 
+    def grad_stats(self, clip_norm, clip_mode):
+        """Gradient summaries of the last clip_rmsprop (actor_learner.py:85-87, logger_utils.py:23-33): dict with
+        mean / stddev / max / min of the raw and of the clipped flat gradient, and global_norm.  Synchronises."""
+        out = torch.zeros(8, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.paac_grad_stats(self.handle, ctypes.c_void_p(out.data_ptr()), _stream()), "paac_grad_stats")
+        s, ss, mx, mn = [float(v) for v in out.cpu().numpy()[:4].astype(np.float64)]
+        n = float(self.layout["total_unpadded"])
+        mean = s / n
+        std = max(ss / n - mean * mean, 0.0) ** 0.5
+        gn = ss ** 0.5
+        f = 1.0
+        if clip_mode == _lib.CLIP_GLOBAL and gn > 0.0:
+            f = clip_norm * min(1.0 / gn, 1.0 / clip_norm)
+        return {"global_norm": gn,
+                "raw_gradients": {"mean": mean, "stddev": std, "max": mx, "min": mn},
+                "clipped_gradients": {"mean": mean * f, "stddev": std * f, "max": mx * f, "min": mn * f}}
+
     def debug_activation(self, what, batch):
         out = torch.empty(batch * 20 * 20 * 64, dtype=torch.float32, device=self.device)
         n = self.lib.paac_debug_activation(self.handle, int(what), int(batch), ctypes.c_void_p(out.data_ptr()), _stream())

@@ -4,6 +4,9 @@ place of the TensorBoard summaries (paac.py:130-135,176-180; actor_learner.py:85
 metrics.jsonl, one object per line:
   {"kind": "progress", "global_step", "steps_per_s", "steps_per_s_avg", "last_10_rewards_avg", "lr", "grad_norm",
    "loss", "actor_loss", "critic_loss", "entropy", "time"}         -- every 2048/emulator_counts cycles (paac.py:172)
+  {"kind": "gradients", "global_step", "global_norm", "raw_gradients": {"mean","stddev","max","min"},
+   "clipped_gradients": {...}}                                     -- with every progress record: the summaries of
+                                                                     actor_learner.py:85-87 / logger_utils.py:23-33
   {"kind": "episode", "global_step", "reward", "length"}          -- one per finished episode (paac.py:130-135)
 """
 import json

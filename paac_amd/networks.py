@@ -43,6 +43,19 @@ def resolve_device(device):
     return torch.device("cuda", idx)
 
 
+def initial_values(layout, rng):
+    """{tensor name: float32 array}: every tensor ~ U(-d, d) with d = 1/sqrt(fan-in of ITS LAYER) -- conv: kh*kw*cin
+    (networks.py:24-33, the conv bias uses the same d, :16), fc: number of inputs (networks.py:63-70, bias :53).
+    Layout order is weights then biases per layer, so a bias takes the fan-in of the weight tensor before it."""
+    values, fan_in = {}, None
+    for t in layout["tensors"]:
+        if t["name"].endswith("weights"):
+            fan_in = int(np.prod(t["shape"][:-1]))
+        d = 1.0 / np.sqrt(fan_in)
+        values[t["name"]] = rng.uniform(-d, d, size=t["shape"]).astype(np.float32)
+    return values
+
+
 class Network(object):
     ARCH = None
 
@@ -87,17 +100,17 @@ class Network(object):
         return {t["name"]: host[t["offset"]:t["offset"] + t["size"]].reshape(t["shape"]).copy()
                 for t in self.layout["tensors"]}
 
+    def make_saver(self, max_to_keep=5):
+        """Saver over this network's variables under the reference's checkpoint names
+        ('local_learning_1/conv1_weights' ... 'local_learning_2/critic_output_biases', session.checkpoint_key)."""
+        from .session import Saver, checkpoint_key, tensor_of_key
+        return Saver(lambda: {checkpoint_key(self.name, k): v for k, v in self.get_parameters().items()},
+                     lambda d: self.set_parameters({tensor_of_key(k)[0]: v for k, v in d.items()}),
+                     max_to_keep=max_to_keep)
+
     def initialize(self, rng=None):
-        """'torch' init of the reference (networks.py:24-46,63-81): U(-d, d), d = 1/sqrt(fan_in) for W and b."""
-        rng = np.random.RandomState() if rng is None else rng
-        named = {}
-        fan_in = 1
-        for t in self.layout["tensors"]:
-            if t["name"].endswith("weights"):
-                fan_in = int(np.prod(t["shape"][:-1]))
-            d = 1.0 / np.sqrt(fan_in)
-            named[t["name"]] = rng.uniform(-d, d, size=t["shape"]).astype(np.float32)
-        self.set_parameters(named)
+        """'torch' initialisation of the reference (the default of networks.py:12-13,49-50)."""
+        self.set_parameters(initial_values(self.layout, np.random.RandomState() if rng is None else rng))
 
     def init(self, checkpoint_folder, saver, session):
         """networks.py:122-135: restore the latest checkpoint if there is one (step parsed from the file

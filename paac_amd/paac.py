@@ -312,6 +312,8 @@ class PAACLearner(ActorLearner):
         if self.metrics is None:
             return
         loss = self.loss_dev.cpu().numpy()
+        stats = self.ctx.grad_stats(self.clip_norm, self.clip_mode)      # actor_learner.py:85-87 summaries
+        self.metrics.write("gradients", global_step=int(self.global_step), **stats)
         self.metrics.write("progress", global_step=int(self.global_step), steps_per_s=float(steps_per_s),
                            steps_per_s_avg=float(steps_per_s_avg), last_10_rewards_avg=float(last_ten),
                            lr=float(self.lr_dev.item()), grad_norm=float(self.gnorm_dev.item()), loss=float(loss[0]),
@@ -511,6 +513,8 @@ class PAACLearner(ActorLearner):
                                       values=d_values.cpu().numpy(), global_step=self.global_step)
                 if getattr(self.args, "feed_callback", None):
                     self.args.feed_callback(self.last_feed)
+            if getattr(self.args, "cycle_callback", None):      # bench hook: one call per finished cycle, nothing copied
+                self.args.cycle_callback(self.global_step)
             counter += 1
             if counter % (2048 / self.emulator_counts) == 0:
                 curr_time = time.time()

@@ -14,30 +14,71 @@ import torch
 from . import hip_ops
 
 
+def variable_scope(scope, tensor_name):
+    """TensorFlow scope of a variable as the reference's graph names it: the nested tf.name_scope(self.name) blocks
+    put the trunk under '<name>_1' (networks.py:111,144,160) and the heads under '<name>_2' (policy_v_network.py:16) --
+    the keys of pretrained/*/checkpoints/*.index ('local_learning_1/conv1_weights', 'local_learning_2/actor_output_biases')."""
+    return "%s_%d" % (scope, 2 if tensor_name.startswith(("actor_output", "critic_output")) else 1)
+
+
+def checkpoint_key(scope, tensor_name, slot=None):
+    """slot: None (the variable), 'OptimizerVariables' (RMSProp ms) or 'OptimizerVariables_1' (momentum)
+    (actor_learner.py:31-34: RMSPropOptimizer(..., name='OptimizerVariables') names its slots after itself)."""
+    key = "%s/%s" % (variable_scope(scope, tensor_name), tensor_name)
+    return key if slot is None else "%s/%s" % (key, slot)
+
+
+def tensor_of_key(key):
+    """-> (tensor name, slot or None); also accepts the un-numbered '<scope>/<tensor>' keys of round-1 checkpoints."""
+    parts = key.split("/")
+    slot = parts[2] if len(parts) > 2 else None
+    return parts[1], slot
+
+
+def _step_of(path):
+    return int(path[path.rindex('-') + 1:].split('.')[0])
+
+
 class Saver(object):
-    """Stand-in for tf.train.Saver over .npz files whose keys are the reference's variable names
-    ('<scope>/<tensor name>', optimizer slots '<...>/OptimizerVariables' and '<...>/OptimizerVariables_1',
-    actor_learner.py:26-27,79-82)."""
+    """Stand-in for tf.train.Saver over .npz files whose keys are the reference's variable names (checkpoint_key;
+    actor_learner.py:26-27,79-82).  Files are named '-<global step>.npz' like the reference's '-<global step>' bundles
+    (networks.py:134 parses the step from the name).  A save is atomic (temporary file + rename) and older files are
+    pruned only afterwards; a truncated or unreadable file left by a killed run is skipped on resume."""
 
     def __init__(self, get_arrays, set_arrays, max_to_keep=5):
         self.get_arrays, self.set_arrays, self.max_to_keep = get_arrays, set_arrays, max_to_keep
 
     @staticmethod
-    def latest_checkpoint(folder):
+    def _readable(path):
+        try:
+            with np.load(path, allow_pickle=False) as z:
+                return len(z.files) > 0
+        except Exception:
+            return False
+
+    @staticmethod
+    def checkpoints(folder):
         import glob
         import os
-        files = glob.glob(os.path.join(folder, "-*.npz"))
-        if not files:
-            return None
-        return max(files, key=lambda p: int(p[p.rindex('-') + 1:].split('.')[0]))
+        return sorted(glob.glob(os.path.join(folder, "-*.npz")), key=_step_of)
+
+    @staticmethod
+    def latest_checkpoint(folder):
+        for path in reversed(Saver.checkpoints(folder)):
+            if Saver._readable(path):
+                return path
+        return None
 
     def save(self, session, folder, global_step):
-        import glob
         import os
         path = os.path.join(folder, "-%d.npz" % int(global_step))
-        np.savez(path, **self.get_arrays())
-        old = sorted(glob.glob(os.path.join(folder, "-*.npz")), key=lambda p: int(p[p.rindex('-') + 1:].split('.')[0]))
-        for p in old[:-self.max_to_keep]:
+        tmp = os.path.join(folder, ".tmp-%d-%d.npz" % (int(global_step), os.getpid()))
+        with open(tmp, "wb") as f:
+            np.savez(f, **self.get_arrays())
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+        for p in self.checkpoints(folder)[:-self.max_to_keep]:
             os.remove(p)
         return path
 

@@ -18,100 +18,107 @@ import numpy as np
 
 from . import hip_ops, logger_utils
 from .paac import PAACLearner
-from .session import Saver, Session
+from .session import Session
 from .train import get_network_and_environment_creator
 
-
-def get_save_frame(name):
-    try:
-        import imageio
-    except ImportError:
-        raise ImportError("--gif_name needs the imageio package")
-    writer = imageio.get_writer(name + '.gif', fps=30)
-
-    def get_frame(frame):
-        writer.append_data(frame)
-
-    return get_frame
+# (option strings, dest, default, type, required, help) -- names and defaults are upstream's (test.py:22-30)
+FLAGS = (
+    (("-f", "--folder"), "folder", None, str, True, "training folder: holds args.json and checkpoints/"),
+    (("-tc", "--test_count"), "test_count", 1, int, False, "number of environments, one scored episode each"),
+    (("-np", "--noops"), "noops", 30, int, False, "upper bound of the random number of no-op steps before play"),
+    (("-gn", "--gif_name"), "gif_name", None, str, False, "record every screen of environment i into <name><i>.gif"),
+    (("-gf", "--gif_folder"), "gif_folder", "", str, False, "directory the gifs are written to"),
+    (("-d", "--device"), "device", "/gpu:0", str, False, "'/gpu:N': which MI355X evaluates the policy"),
+)
 
 
 def get_arg_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-f', '--folder', type=str, help="Folder where to save the debugging information.", dest="folder", required=True)
-    parser.add_argument('-tc', '--test_count', default='1', type=int, help="The amount of tests to run on the given network", dest="test_count")
-    parser.add_argument('-np', '--noops', default=30, type=int, help="Maximum amount of no-ops to use", dest="noops")
-    parser.add_argument('-gn', '--gif_name', default=None, type=str, help="If provided, a gif will be produced and stored with this name", dest="gif_name")
-    parser.add_argument('-gf', '--gif_folder', default='', type=str, help="The folder where to save gifs.", dest="gif_folder")
-    parser.add_argument('-d', '--device', default='/gpu:0', type=str, help="Device to be used ('/gpu:0', '/gpu:1',...)", dest="device")
+    parser = argparse.ArgumentParser(description="Score the latest checkpoint of a training folder.")
+    for options, dest, default, kind, required, text in FLAGS:
+        parser.add_argument(*options, dest=dest, default=default, type=kind, required=required, help=text)
     return parser
 
 
+class GifRecorder(object):
+    """on_new_frame hook (environment.py:34-39): appends every screen an environment shows to one gif (30 fps)."""
+
+    def __init__(self, path):
+        try:
+            import imageio
+        except ImportError:
+            raise ImportError("--gif_name needs the imageio package")
+        self.writer = imageio.get_writer(path + '.gif', fps=30)
+
+    def __call__(self, frame):
+        self.writer.append_data(frame)
+
+
+def get_save_frame(name):
+    """Upstream's name for the hook factory (test.py:12-20)."""
+    return GifRecorder(name)
+
+
 def evaluate(network, env_creator, session, test_count, noops=30, max_steps=None, on_new_frame=None):
-    """-> float32 [test_count] scores of the first episode of each environment."""
+    """-> float32 [test_count]: score of the FIRST episode of each environment under the sampled policy."""
     environments = [env_creator.create_environment(i) for i in range(test_count)]
     if on_new_frame is not None:
         for i, environment in enumerate(environments):
             environment.on_new_frame = on_new_frame(i)
-    states = np.asarray([environment.get_initial_state() for environment in environments])
-    if noops != 0:
-        for i, environment in enumerate(environments):
-            for _ in range(random.randint(0, noops)):
-                state, _, _ = environment.next(environment.get_noop())
-                states[i] = state
-    episodes_over = np.zeros(test_count, dtype=bool)
-    rewards = np.zeros(test_count, dtype=np.float32)
+    states = np.stack([environment.get_initial_state() for environment in environments])
+    for i, environment in enumerate(environments):          # random start: 0..noops no-op steps (test.py:69-73)
+        for _ in range(random.randint(0, noops) if noops else 0):
+            states[i] = environment.next(environment.get_noop())[0]
+    scores = np.zeros(test_count, dtype=np.float32)
+    playing = list(range(test_count))
     steps = 0
-    while not episodes_over.all() and (max_steps is None or steps < max_steps):
+    while playing and (max_steps is None or steps < max_steps):
         actions, _, _ = PAACLearner.choose_next_actions(network, env_creator.num_actions, states, session)
-        for j, environment in enumerate(environments):
-            if episodes_over[j]:
-                continue
-            state, r, episode_over = environment.next(actions[j])
-            states[j] = state
-            rewards[j] += r
-            episodes_over[j] = episode_over
+        still = []
+        for j in playing:
+            states[j], reward, over = environments[j].next(actions[j])
+            scores[j] += reward
+            if not over:
+                still.append(j)
+        playing = still
         steps += 1
-    return rewards
+    return scores
+
+
+def restore_settings(cli):
+    """The training run's args.json with the evaluation overrides of test.py:32-48 applied on top."""
+    settings = argparse.Namespace(**vars(cli))
+    for k, v in logger_utils.load_args(os.path.join(cli.folder, 'args.json')).items():
+        setattr(settings, k, v)
+    overrides = dict(device=cli.device, debugging_folder='/tmp/logs', max_global_steps=0, random_start=False,
+                     single_life_episodes=False, actor_id=0)
+    if cli.gif_name:
+        overrides["visualize"] = 1
+    for k, v in overrides.items():
+        setattr(settings, k, v)
+    return settings
 
 
 def main(argv=None):
-    args = get_arg_parser().parse_args(argv)
-    arg_file = os.path.join(args.folder, 'args.json')
-    device = args.device
-    for k, v in logger_utils.load_args(arg_file).items():
-        setattr(args, k, v)
-    args.max_global_steps = 0
-    df = args.folder
-    args.debugging_folder = '/tmp/logs'
-    args.device = device
-    args.random_start = False
-    args.single_life_episodes = False
-    if args.gif_name:
-        args.visualize = 1
-    args.actor_id = 0
-    rng = np.random.RandomState(int(time.time()))
-    seed = int(rng.randint(1000))
-
+    cli = get_arg_parser().parse_args(argv)
+    args = restore_settings(cli)
+    seed = int(np.random.RandomState(int(time.time())).randint(1000))
     network_creator, env_creator = get_network_and_environment_creator(args, random_seed=seed)
     network = network_creator()
-    scope = network.name
-    saver = Saver(lambda: {"%s/%s" % (scope, k): v for k, v in network.get_parameters().items()},
-                  lambda d: network.set_parameters({k.split("/", 1)[1]: v for k, v in d.items()}))
     ctx = hip_ops.Context(network.arch_id, env_creator.num_actions, max_batch=max(1, args.test_count),
                           device_index=network.torch_device.index or 0)
     session = Session(network, ctx)
-    network.init(os.path.join(df, 'checkpoints'), saver, session)
+    network.init(os.path.join(cli.folder, 'checkpoints'), network.make_saver(), session)
     hook = None
     if args.gif_name:
         hook = lambda i: get_save_frame(os.path.join(args.gif_folder, args.gif_name + str(i)))
-    rewards = evaluate(network, env_creator, session, args.test_count, noops=args.noops, on_new_frame=hook)
-    session.close()
-    ctx.close()
+    try:
+        rewards = evaluate(network, env_creator, session, args.test_count, noops=args.noops, on_new_frame=hook)
+    finally:
+        session.close()
+        ctx.close()
     print('Performed {} tests for {}.'.format(args.test_count, args.game))
-    print('Mean: {0:.2f}'.format(np.mean(rewards)))
-    print('Min: {0:.2f}'.format(np.min(rewards)))
-    print('Max: {0:.2f}'.format(np.max(rewards)))
-    print('Std: {0:.2f}'.format(np.std(rewards)))
+    for label, stat in (('Mean', np.mean), ('Min', np.min), ('Max', np.max), ('Std', np.std)):
+        print('{0}: {1:.2f}'.format(label, stat(rewards)))
     return rewards
 
 

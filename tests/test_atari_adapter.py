@@ -24,8 +24,8 @@ def emu_args(**kw):
 class ReferenceFlow(object):
     """atari_emulator.py:60-112 restated step by step on the oracle's FramePool / ObservationPool / max_resize."""
 
-    def __init__(self, actor_id, args):
-        self.ale = FakeALE()
+    def __init__(self, actor_id, args, ale=None):
+        self.ale = FakeALE() if ale is None else ale
         self.ale.setInt(b"random_seed", args.random_seed * (actor_id + 1))
         self.legal = self.ale.getMinimalActionSet()
         self.args = args
@@ -183,6 +183,25 @@ def test_device_preprocessing_loop_equals_host_loop():
     for c, (a, b) in enumerate(zip(feeds[False], feeds[True])):
         assert np.array_equal(a["states"], b["states"]), "cycle %d: observations differ" % c
         assert np.array_equal(a["actions"], b["actions"]) and np.array_equal(a["y"], b["y"])
+    # ... and against the ORACLE: the reference's episode flow (atari_emulator.py:60-112, emulator_runner.py:24-31)
+    # restated on the oracle's FramePool / ObservationPool / PIL-nearest LUT, driven by the recorded actions -- every
+    # observation the device-preprocessing loop trained on, bit for bit, resets included
+    random.seed(5)
+    ref_args = emu_args(random_start=True, single_life_episodes=True)
+    flows = [ReferenceFlow(i, ref_args, ale=FakeALE(episode_frames=110)) for i in range(N)]
+    shared = [f.initial() for f in flows]
+    resets = 0
+    for c, feed in enumerate(feeds[True]):
+        states = feed["states"].reshape(T, N, 84, 84, 4)
+        actions = feed["actions"].reshape(T, N)
+        for t in range(T):
+            for e in range(N):
+                assert np.array_equal(states[t, e], shared[e]), "cycle %d step %d env %d" % (c, t, e)
+            for e in range(N):                   # emulator_runner.py:24-31: step, auto-reset on terminal
+                obs, _, over = flows[e].next(int(actions[t, e]))
+                shared[e] = flows[e].initial() if over else obs
+                resets += bool(over)
+    assert resets >= N
 
 
 def test_evaluation_loop_freezes_finished_environments(monkeypatch):

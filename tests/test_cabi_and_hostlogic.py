@@ -160,3 +160,72 @@ def test_runners_host_batching():
         r.stop()
         for p in r.runners:
             p.join(timeout=5)
+
+
+def test_checkpoint_keys_are_the_reference_index():
+    """The saver's key for every tensor of the NIPS / A=4 layout (and both optimizer slots) == the key set and shapes
+    of /root/reference/pretrained/breakout/checkpoints/-80000000.index (actor_learner.py:26-27,79-82)."""
+    index = "/root/reference/pretrained/breakout/checkpoints/-80000000.index"
+    if not os.path.exists(index):
+        pytest.skip("reference not mounted")
+    import tfproto
+    from oracle import network as onet
+    from paac_amd import _lib
+    from paac_amd.session import checkpoint_key, tensor_of_key
+    lay = _lib.param_layout(_lib.ARCH_NIPS, 4)
+    ours = {}
+    for t in lay["tensors"]:
+        for slot in (None, "OptimizerVariables", "OptimizerVariables_1"):
+            key = checkpoint_key("local_learning", t["name"], slot)
+            ours[key] = tuple(t["shape"])
+            assert tensor_of_key(key) == (t["name"], slot)
+    assert ours == tfproto.bundle_entries(index)
+    assert [t["name"] for t in lay["tensors"]] == [n for n, _ in onet.param_shapes("NIPS", 4)]
+
+
+def test_saver_is_atomic_and_skips_a_torn_file(tmp_path):
+    """A kill during a save must not break resume: saves go through a temporary file + rename, older files are pruned
+    afterwards, and latest_checkpoint skips a truncated newest file."""
+    from paac_amd.session import Saver
+    store = {"local_learning_1/conv1_biases": np.arange(4, dtype=np.float32)}
+    got = {}
+    saver = Saver(lambda: store, got.update, max_to_keep=2)
+    folder = str(tmp_path)
+    for step in (10, 20, 30):
+        store["local_learning_1/conv1_biases"] = np.full(4, step, dtype=np.float32)
+        saver.save(None, folder, step)
+    names = sorted(os.listdir(folder))
+    assert names == ["-20.npz", "-30.npz"]                        # max_to_keep, no temporaries left behind
+    with open(os.path.join(folder, "-40.npz"), "wb") as f:         # a torn newest file
+        f.write(open(os.path.join(folder, "-30.npz"), "rb").read()[:40])
+    latest = Saver.latest_checkpoint(folder)
+    assert latest.endswith("-30.npz")
+    saver.restore(None, latest)
+    assert np.array_equal(got["local_learning_1/conv1_biases"], np.full(4, 30, dtype=np.float32))
+    assert Saver.latest_checkpoint(str(tmp_path / "missing")) is None
+
+
+@pytest.mark.parametrize("arch,A", [("NIPS", 4), ("NATURE", 18)])
+def test_weight_init_ranges(arch, A):
+    """Row a10 (networks.py:24-46,63-81): every tensor is drawn from U(-d, d), d = 1/sqrt(fan_in); a conv bias uses its
+    conv's kh*kw*cin, an fc bias its fc's input count (not the bias' own size)."""
+    from paac_amd import _lib, networks
+    lay = _lib.param_layout(_lib.ARCH_NIPS if arch == "NIPS" else _lib.ARCH_NATURE, A)
+    vals = networks.initial_values(lay, np.random.RandomState(0))
+    fan = {"conv1": 8 * 8 * 4}
+    if arch == "NIPS":
+        fan.update(conv2=4 * 4 * 16, fc3=2592, actor_output=256, critic_output=256)
+    else:
+        fan.update(conv2=4 * 4 * 32, conv3=3 * 3 * 64, fc4=3136, actor_output=512, critic_output=512)
+    assert len(vals) == len(lay["tensors"]) == 2 * len(fan)
+    for t in lay["tensors"]:
+        layer = t["name"].rsplit("_", 1)[0]
+        d = 1.0 / np.sqrt(fan[layer])
+        v = vals[t["name"]]
+        assert v.dtype == np.float32 and v.shape == tuple(t["shape"])
+        assert np.abs(v).max() <= d, t["name"]
+        if v.size >= 32:                                  # the range is used, not a narrower one
+            assert np.abs(v).max() > 0.8 * d and abs(v.mean()) < 0.25 * d, t["name"]
+    # two draws differ (unseeded default), a seeded draw repeats
+    again = networks.initial_values(lay, np.random.RandomState(0))
+    assert all(np.array_equal(vals[k], again[k]) for k in vals)

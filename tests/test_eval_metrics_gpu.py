@@ -42,9 +42,15 @@ def test_train_writes_metrics_then_eval_restores_checkpoint(capsys):
     assert rewards.shape == (3,) and np.isfinite(rewards).all()
 
     # the harness restored exactly what the learner saved
-    from paac_amd.session import Saver
+    from paac_amd.session import Saver, checkpoint_key
     path = Saver.latest_checkpoint(os.path.join(folder, "checkpoints"))
     assert path.endswith("-%d.npz" % (130 * 160))
     with np.load(path) as z:
+        assert "local_learning_1/conv1_weights" in z.files and "local_learning_2/actor_output_biases" in z.files
         for k, v in want.items():
-            assert np.array_equal(z["local_learning/" + k], v)
+            assert np.array_equal(z[checkpoint_key("local_learning", k)], v)
+    opt = Saver.latest_checkpoint(os.path.join(folder, "optimizer_checkpoints"))
+    with np.load(opt) as z:       # both RMSProp slots of every variable, under the reference's names
+        assert len(z.files) == 2 * len(want)
+        assert "local_learning_1/fc3_weights/OptimizerVariables" in z.files
+        assert "local_learning_2/critic_output_weights/OptimizerVariables_1" in z.files

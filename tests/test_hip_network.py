@@ -211,6 +211,45 @@ def test_clip_rmsprop_parity(mode, gscale, momentum):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["mixed", "all_negative", "negative_with_real_zeros"])
+def test_grad_stats_are_the_reference_summaries(case):
+    """actor_learner.py:85-87 -> logger_utils.py:23-33: mean / stddev / max / min of the flat raw and clipped gradients
+    (the reference's flat gradient has no alignment pads: the pad zeros must not leak into max / min)."""
+    from paac_amd import hip_ops, _lib
+    ctx = hip_ops.Context(ARCH_ID["NATURE"], 6, max_batch=8)       # A=6: bias tensors end in pads
+    lay = ctx.layout
+    assert lay["total"] > lay["total_unpadded"]
+    n = lay["total"]
+    rs = np.random.RandomState(8)
+    flat = np.zeros(n, dtype=np.float32)
+    real = []
+    for t in lay["tensors"]:
+        v = (rs.randn(t["size"]) * 0.01).astype(np.float32)
+        if case != "mixed":
+            v = -np.abs(v) - np.float32(1e-6)
+        if case == "negative_with_real_zeros" and t["size"] > 100:
+            v[::17] = 0.0
+        flat[t["offset"]:t["offset"] + t["size"]] = v
+        real.append(v)
+    real = np.concatenate(real).astype(np.float64) * 0.5           # grad_scale 0.5 (two ranks)
+    z = lambda: torch.zeros(n, device="cuda")
+    ctx.clip_rmsprop(z(), torch.from_numpy(flat).cuda(), torch.ones(n, device="cuda"), z(),
+                     torch.tensor([0.01], device="cuda"), 0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL, 0.5)
+    got = ctx.grad_stats(3.0, _lib.CLIP_GLOBAL)
+    gn = np.sqrt((real ** 2).sum())
+    f = 3.0 * min(1.0 / gn, 1.0 / 3.0)
+    assert abs(got["global_norm"] - gn) / gn < 1e-5
+    for name, x in (("raw_gradients", real), ("clipped_gradients", real * f)):
+        want = dict(mean=x.mean(), stddev=np.sqrt(((x - x.mean()) ** 2).mean()), max=x.max(), min=x.min())
+        for k, w in want.items():
+            assert abs(got[name][k] - w) <= 2e-5 * max(abs(w), np.abs(x).max() * 1e-2), (case, name, k, got[name][k], w)
+    if case == "all_negative":
+        assert got["raw_gradients"]["max"] < 0.0                   # no pad zero leaked in
+    if case == "negative_with_real_zeros":
+        assert got["raw_gradients"]["max"] == 0.0
+    ctx.close()
+
+
 def test_errors_are_loud():
     from paac_amd import hip_ops, _lib
     ctx = hip_ops.Context(1, 4, max_batch=8)
