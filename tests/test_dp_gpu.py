@@ -95,3 +95,82 @@ def test_bench_two_rank_rehearsal():
     assert out["n_gpus"] == 2 and out["steps"] == 12 and out["scaling"] == "weak" and out["finite_params"]
     assert out["config"]["global_envs"] == 64 and out["cpu_baseline"] is None
     assert out["roofline"]["bound"] in ("mfma", "hbm") and out["value"] > 0
+
+
+_RCCL_SMOKE = r"""
+import os, sys, tempfile
+import numpy as np
+sys.path.insert(0, %(root)r)
+from paac_amd import parallel, train
+args = train.get_arg_parser().parse_args([])
+assert parallel.init_from_env(args) == 1 and args.device == "/gpu:0"
+import torch
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+from paac_amd.paac import DeviceRollout, PAACLearner
+args.game, args.arch = "breakout", "NATURE"
+args.emulator_counts, args.max_local_steps, args.emulator_workers = 8, 5, 0
+args.max_global_steps = 1 << 40
+args.synthetic_terminal_p = 0.1
+out = {}
+for mode in ("plain", "split", "single"):
+    os.environ["PAAC_FORCE_COLLECTIVES"] = "0" if mode == "plain" else "1"
+    os.environ["PAAC_ALLREDUCE"] = "single" if mode == "single" else "split"
+    args.debugging_folder = tempfile.mkdtemp(prefix="paac_rccl_")
+    nc, ec = train.get_network_and_environment_creator(args)
+    L = PAACLearner(nc, ec, args)
+    L.network.initialize(np.random.RandomState(0))
+    np.random.seed(4)
+    ro = DeviceRollout(L, ec.device_env_spec, sampler="numpy", use_graph=True)
+    assert ro.phased == (mode != "plain")
+    ro.run_cycles(7)
+    ro.synchronize()
+    out[mode] = (L.network.params.cpu().numpy().copy(), ro.actions.cpu().numpy().copy(), int(ro.global_step_dev.item()))
+    assert (ro.graph_ua[0] is not None) == (mode != "plain")
+    assert (ro.graph_conv[0] is not None) == (mode == "split")
+    ro.close()
+for mode in ("split", "single"):
+    assert np.array_equal(out[mode][0], out["plain"][0]), mode + ": weights differ from the unphased run"
+    assert np.array_equal(out[mode][1], out["plain"][1]) and out[mode][2] == out["plain"][2]
+parallel.shutdown()
+print("RCCL_SMOKE_OK")
+"""
+
+
+def test_phased_exchange_runs_under_rccl_world_of_one():
+    """The data-parallel cycle -- graph_a / graph_conv / graph_ua around stream-ordered RCCL all-reduces
+    (DeviceRollout._exchange), both exchange modes -- executed under backend "nccl" on this one GPU (a world of one
+    with the collectives forced on): the all-reduce of one rank is the identity, so the weights after 7 cycles must
+    equal the plain single-process replay bit for bit."""
+    import subprocess
+    env = dict(os.environ, PAAC_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    res = subprocess.run([sys.executable, "-c", _RCCL_SMOKE % dict(root=ROOT)], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "RCCL_SMOKE_OK" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
+
+
+def test_train_module_under_torchrun_two_ranks():
+    """`python -m torch.distributed.run --nproc-per-node 2 -m paac_amd.train ...` (both ranks on this one GPU, gradients
+    over gloo): train.main joins the group before touching the GPU, rank 0 alone writes args.json, checkpoints and
+    metrics, both ranks finish the same number of cycles, and the run resumes from the checkpoint."""
+    import json
+    import subprocess
+    folder = tempfile.mkdtemp(prefix="paac_dp_train_")
+    env = dict(os.environ, PAAC_DIST_BACKEND="gloo", PAAC_DIST_SINGLE_DEVICE="1")
+    steps = 2 * 8 * 5 * 6                     # 2 ranks x 8 envs x t_max 5 x 6 cycles
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "-m", "paac_amd.train", "-g", "breakout", "--arch", "NATURE",
+           "-ec", "8", "-ew", "0", "--max_global_steps", str(steps), "-df", folder]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert res.stdout.count("Starting training (2 data-parallel ranks)") == 2
+    assert json.load(open(os.path.join(folder, "args.json")))["emulator_counts"] == 8
+    assert os.listdir(os.path.join(folder, "checkpoints")) == ["-%d.npz" % steps]
+    assert os.listdir(os.path.join(folder, "optimizer_checkpoints")) == ["-%d.npz" % steps]
+    # resume: both ranks restore step `steps`, run 2 more cycles, rank 0 writes the next checkpoint
+    cmd[cmd.index("--max_global_steps") + 1] = str(steps + 2 * 80)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "Starting training at Step %d" % steps in res.stdout
+    assert sorted(os.listdir(os.path.join(folder, "checkpoints"))) == sorted(["-%d.npz" % steps, "-%d.npz" % (steps + 160)])
