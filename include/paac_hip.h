@@ -98,6 +98,16 @@ int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uin
 int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* values,
                        paac_stream_t stream);
 
+/* Conv-weight packing.  The Nature conv layers run as one fused launch that reads the conv weights pre-split into bf16
+ * planes (an internal copy owned by the ctx).  By default every paac_forward* / paac_train_forward / paac_loss_backward
+ * call refreshes that copy from `params` first (one small extra launch), so a caller may change `params` at any time.
+ * A caller that owns every write to `params` can switch to managed mode: paac_set_managed_weights(ctx, 1) -- then the
+ * copy is refreshed only by paac_clip_rmsprop (right behind the optimizer step) and by an explicit paac_pack_weights
+ * (call it after initialising, restoring or broadcasting `params`); in managed mode the acting forwards also stop
+ * keeping the conv1 / conv2 activations (only the training forward keeps them, for the backward pass). */
+int paac_pack_weights(paac_ctx* ctx, const float* params, paac_stream_t stream);
+int paac_set_managed_weights(paac_ctx* ctx, int on);
+
 /* Loss + gradients of policy_v_network.py:29-57 through the whole network (what
  * optimizer.compute_gradients(loss), actor_learner.py:44, evaluates): runs the training forward
  * on `states` (unless forward_done != 0: paac_train_forward already ran on the same batch), then backward.
@@ -210,7 +220,7 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
 
 /* Tuning (tools/tune_gemm.py): override the launch configuration of GEMM op `op` (0 conv1_fwd, 1 conv2_fwd,
  * 2 conv3_fwd, 3 fc_fwd, 4 fc_wgrad, 5 fc_dgrad, 6 conv3_wgrad, 7 conv3_dgrad, 8 conv2_wgrad, 9 conv2_dgrad,
- * 10 conv1_wgrad) for batch class 0 (batch <= 64), 1 (batch <= 512) or 2: cfg = index into the family's configuration table
+ * 10 conv1_wgrad, 11 conv tower: cfg = regions per sample, 1 / 2 / 4, -1 = by batch) for batch class 0 (batch <= 64), 1 (batch <= 512) or 2: cfg = index into the family's configuration table
  * (-1 = size heuristic), ksplit = blockIdx.z K split (0 = heuristic), xcd_dim = grid dimension tied to the XCD. */
 int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int ksplit, int xcd_dim);
 int paac_debug_get_tuning(paac_ctx* ctx, int op, int batch_class, int* cfg, int* ksplit, int* xcd_dim);
@@ -224,7 +234,7 @@ int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);
  * processed and its duration in ms (up to max_events; the internal table holds 8192 launches); returns the
  * number of records written and clears the table.  The entry points that take no ctx (environment step, samplers,
  * n-step returns, preprocessing) are recorded in the table of the ctx profiling was last enabled on. */
-#define PAAC_PROF_FAMILIES 22
+#define PAAC_PROF_FAMILIES 23
 int paac_prof_enable(paac_ctx* ctx, int on);
 int paac_prof_read(paac_ctx* ctx, int32_t* family_out, int32_t* batch_out, float* ms_out, int max_events);
 const char* paac_prof_name(int family);

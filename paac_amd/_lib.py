@@ -47,6 +47,8 @@ _SIGNATURES = {
     "paac_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "paac_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "paac_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "paac_set_managed_weights": (c_int, [c_void_p, c_int]),
     "paac_grad_stats": (c_int, [c_void_p, c_void_p, c_void_p]),
     "paac_clip_rmsprop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float,
                                   c_float, c_float, c_float, c_int, c_float, c_void_p, c_void_p]),

@@ -76,6 +76,11 @@ class ActorLearner(object):
                                    max_batch=self.emulator_counts * (self.max_local_steps + 1),   # + bootstrap rows
                                    device_index=dev.index or 0)
         self.session = Session(self.network, self.ctx, learner=self)
+        # the learner owns every write to the parameters: the optimizer step re-packs the conv weights for the fused conv
+        # launch itself; host-side writes (set_parameters, restore, broadcast) go through weights_changed
+        self.ctx.set_managed_weights(True)
+        self.network.weights_changed = lambda: self.ctx.pack_weights(self.network.params)
+        self.ctx.pack_weights(self.network.params)
 
         self.network_saver = self.network.make_saver()
         self.optimizer_saver = Saver(self._get_optimizer_arrays, self._set_optimizer_arrays, max_to_keep=1)
@@ -168,6 +173,7 @@ class ActorLearner(object):
             step = torch.tensor([int(resumed_step)], dtype=torch.int64, device=self.torch_device)
             for t in (self.network.params, self.rms, self.mom, step):
                 parallel.broadcast_(t, src=0)
+            self.network.weights_changed()
             resumed_step = int(step.item())
         return resumed_step          # like upstream, last_saving_step stays 0: a resumed run checkpoints on its first cycle
 

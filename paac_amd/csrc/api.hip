@@ -40,13 +40,14 @@ ArchSpec arch_spec(int arch) {
 }
 
 int64_t wslab_floats_needed(int arch);
+size_t tower_pack_bytes();
 void default_tuning(paac_ctx* c);
 int fc_splits_max();
 
 static const char* kFamilyNames[PAAC_PROF_FAMILIES] = {
     "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "heads_fwd", "heads_bwd", "fc_wgrad", "fc_dgrad",
     "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "misc",
-    "env_step", "sample_env_step", "sample_mt", "sample_philox", "nstep_returns", "preprocess_stack"};
+    "env_step", "sample_env_step", "sample_mt", "sample_philox", "nstep_returns", "preprocess_stack", "conv_tower"};
 
 }  // namespace paac
 
@@ -153,6 +154,13 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
   PAAC_CHECK_HIP(hipMalloc(&c->partials, 4096 * sizeof(float)));
   PAAC_CHECK_HIP(hipMemset(c->partials, 0, 4096 * sizeof(float)));
+  {
+    const char* v = getenv("PAAC_TOWER");
+    c->tower_on = (cfg->arch == PAAC_ARCH_NATURE) && !(v && *v && atoi(v) == 0);
+    c->managed_weights = 0;
+    c->tower_pack = nullptr;
+    if (c->tower_on) PAAC_CHECK_HIP(hipMalloc(&c->tower_pack, tower_pack_bytes()));
+  }
   c->ev_start = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
   c->ev_stop = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
   c->ev_family = new int[paac_ctx::PROF_MAX_EVENTS];
@@ -182,6 +190,7 @@ int paac_destroy(paac_ctx* c) {
   float* bufs[] = {c->dh, c->wslab, c->partials};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
+  if (c->tower_pack) (void)hipFree(c->tower_pack);
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
     if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
     if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -202,6 +211,20 @@ int paac_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int 
   const int rc = launch_forward(ctx, 0, params, states, batch, logits, probs, values, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_pack_weights(paac_ctx* ctx, const float* params, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params, "paac_pack_weights: null argument");
+  const int rc = launch_pack_weights(ctx, params, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_set_managed_weights(paac_ctx* ctx, int on) {
+  PAAC_REQUIRE(ctx, "paac_set_managed_weights: null ctx");
+  ctx->managed_weights = on ? 1 : 0;
   return 0;
 }
 

@@ -50,9 +50,9 @@ enum Family {
   F_HEADS_BWD, F_FC_WGRAD, F_FC_DGRAD, F_CONV3_WGRAD, F_CONV3_DGRAD, F_CONV2_WGRAD, F_CONV2_DGRAD, F_CONV1_WGRAD,
   F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_MISC,
   // the kernels around the network (entry points without a ctx: timed through the ctx profiling was enabled on)
-  F_ENV_STEP, F_SAMPLE_ENV_STEP, F_SAMPLE_MT, F_SAMPLE_PHILOX, F_NSTEP_RETURNS, F_PREPROCESS_STACK
+  F_ENV_STEP, F_SAMPLE_ENV_STEP, F_SAMPLE_MT, F_SAMPLE_PHILOX, F_NSTEP_RETURNS, F_PREPROCESS_STACK, F_CONV_TOWER
 };
-static_assert(F_PREPROCESS_STACK + 1 == PAAC_PROF_FAMILIES, "family count");
+static_assert(F_CONV_TOWER + 1 == PAAC_PROF_FAMILIES, "family count");
 
 }  // namespace paac
 
@@ -73,7 +73,7 @@ struct Workspace {
 namespace paac {
 // GEMM ops of the network (tuning table index) and their launch tuning record.
 enum Op { OP_CONV1_FWD = 0, OP_CONV2_FWD, OP_CONV3_FWD, OP_FC_FWD, OP_FC_WGRAD, OP_FC_DGRAD, OP_CONV3_WGRAD,
-          OP_CONV3_DGRAD, OP_CONV2_WGRAD, OP_CONV2_DGRAD, OP_CONV1_WGRAD, OP_COUNT };
+          OP_CONV3_DGRAD, OP_CONV2_WGRAD, OP_CONV2_DGRAD, OP_CONV1_WGRAD, OP_CONV_TOWER, OP_COUNT };
 struct Tune {
   int cfg;     // index into the family's configuration table, -1 = size heuristic
   int ksplit;  // blockIdx.z K split (slab epilogues), 0 = heuristic
@@ -97,6 +97,11 @@ struct paac_ctx {
   int64_t wslab_floats;
   float* partials; // sum-of-squares partials
   int fc_splits_max;
+  // conv tower (csrc/tower.h, Nature only): conv weights pre-split into bf16 planes in MFMA operand order
+  void* tower_pack;      // kTowerPackVecs x 16 bytes, nullptr when the tower is off
+  int tower_on;          // PAAC_TOWER (default 1)
+  int managed_weights;   // paac_set_managed_weights: 1 = the caller keeps tower_pack current (paac_clip_rmsprop / paac_pack_weights
+                         // re-pack) and acting forwards keep no conv1 / conv2 activations; 0 = every forward re-packs first
   // profiling hooks
   int prof_on;
   static constexpr int PROF_MAX_EVENTS = 8192;
@@ -160,6 +165,7 @@ int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t
                                uint32_t env_offset, int32_t* actions, uint64_t env_seed, uint32_t thresh,
                                uint8_t* stack_out, float* rewards, float* masks, float* ep_reward, int32_t* ep_len,
                                void* finished, hipStream_t s);
+int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s);
 

@@ -949,6 +949,10 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   else
     launch_k(rmsprop_kernel<false>, dim3((n4 + 256 * RMS_U - 1) / (256 * RMS_U)), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
              decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
+  {   // the conv tower's pre-split copy of the conv weights follows every optimizer step
+    const int rc = launch_pack_weights(ctx, params, s);
+    if (rc) return rc;
+  }
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -4,10 +4,13 @@
 // Layout contract: activations NHWC fp32, conv weights HWIO, fc weights [in,out], flatten in HWC order
 // (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
 #include "net_common.h"
+#include "tower.h"
 
 namespace paac {
 
 #ifdef PAAC_DMM_STAMPS
+unsigned long long* g_tower_stamps = nullptr;
+extern "C" void paac_debug_set_tower_stamps(unsigned long long* p) { g_tower_stamps = p; }
 unsigned long long* g_stamps = nullptr;
 int g_stamp_which = -1, g_stamp_calls = 0;
 extern "C" void paac_debug_set_stamps(unsigned long long* p, int which) {
@@ -82,6 +85,59 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Conv tower (tower.h): Nature conv1 -> conv2 -> conv3 in one launch.
+size_t tower_pack_bytes() { return (size_t)kTowerPackVecs * sizeof(bf16x8); }
+
+int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
+  if (!ctx->tower_on) return 0;
+  const paac_layout& L = ctx->layout;
+  constexpr int threads = (8 * 2 + 16 * 4 + 18 * 4) * 64;
+  launch_k(pack_tower_kernel, dim3((threads + 255) / 256), dim3(256), s, PROF_NONE, params + L.offset[0], params + L.offset[2],
+           params + L.offset[4], reinterpret_cast<bf16x8*>(ctx->tower_pack));
+  return 0;
+}
+
+template <class G, bool KEEP>
+static void launch_tower_variant(const TowerArgs& a, hipStream_t s) {
+  launch_k(tower_kernel<G, KEEP>, dim3((unsigned)(a.batch * G::NR)), dim3(512), s, PROF_WHOLE, a);
+}
+
+// keep = also write the fp32 conv1 / conv2 activations (the backward pass and the debug read-back need them)
+static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const uint8_t* states, int batch, bool keep,
+                         hipStream_t s) {
+  const paac_layout& L = ctx->layout;
+  TowerArgs a;
+  a.states = states;
+  const bf16x8* pk = reinterpret_cast<const bf16x8*>(ctx->tower_pack);
+  a.w1p = pk;
+  a.w2p = pk + kTowerW1Vecs;
+  a.w3p = pk + kTowerW1Vecs + kTowerW2Vecs;
+  a.b1 = params + L.offset[1];
+  a.b2 = params + L.offset[3];
+  a.b3 = params + L.offset[5];
+  a.act1 = W.act[0];
+  a.act2 = W.act[1];
+  a.act3 = W.act[2];
+  a.batch = batch;
+#ifdef PAAC_DMM_STAMPS
+  a.stamps = g_tower_stamps;
+#endif
+  // regions per sample: as many as keep the launch within about one round of the 256 CUs
+  const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
+  int regions = (4 * batch <= 288) ? 4 : (2 * batch <= 288) ? 2 : 1;
+  if (force == 1 || force == 2 || force == 4) regions = force;
+  if (regions == 4) {
+    if (keep) launch_tower_variant<TowerGeom<4, 4>, true>(a, s);
+    else launch_tower_variant<TowerGeom<4, 4>, false>(a, s);
+  } else if (regions == 2) {
+    if (keep) launch_tower_variant<TowerGeom<4, 7>, true>(a, s);
+    else launch_tower_variant<TowerGeom<4, 7>, false>(a, s);
+  } else {
+    if (keep) launch_tower_variant<TowerGeom<7, 7>, true>(a, s);
+    else launch_tower_variant<TowerGeom<7, 7>, false>(a, s);
+  }
+}
+
 template <class NT>
 static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
                         float* probs, float* values, const PhiloxArgs& ph, const SynthStepArgs& st, hipStream_t s) {
@@ -108,18 +164,28 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   const float* wc = params + L.offset[t++];
   const float* bc = params + L.offset[t++];
 
-  {
+  bool tower = false;
+  if constexpr (NT::NCONV == 3) tower = ctx->tower_on != 0;
+  if (tower) {
+    if (!ctx->managed_weights) launch_pack_weights(ctx, params, s);
+    ProfScope ps(ctx, F_CONV_TOWER, batch, s);
+    launch_tower(ctx, W, params, states, batch, wsi == 1 || !ctx->managed_weights, s);
+  }
+  if (!tower) {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
     GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)256 * NT::C1 * 4, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
     launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
   }
-  {
+  if (!tower) {
     ProfScope ps(ctx, F_CONV2_FWD, batch, s);
     GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
     launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
   }
   const float* last = W.act[1];
   if constexpr (NT::NCONV == 3) {
+    last = W.act[2];
+  }
+  if constexpr (NT::NCONV == 3) if (!tower) {
     ProfScope ps(ctx, F_CONV3_FWD, batch, s);
     GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
     launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);

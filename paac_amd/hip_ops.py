@@ -158,6 +158,16 @@ class Context(object):
                                               _ptr(gnorm_out, torch.float32, 1, "gnorm_out", True), _stream()),
                    "paac_clip_rmsprop")
 
+    def pack_weights(self, params):
+        """Refresh the ctx's pre-split copy of the conv weights (include/paac_hip.h: paac_pack_weights)."""
+        _lib.check(self.lib.paac_pack_weights(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                              _stream()), "paac_pack_weights")
+
+    def set_managed_weights(self, on=True):
+        """Managed mode: only clip_rmsprop / pack_weights refresh the pre-split copy; acting forwards keep no conv1 /
+        conv2 activations (include/paac_hip.h: paac_set_managed_weights)."""
+        _lib.check(self.lib.paac_set_managed_weights(self.handle, 1 if on else 0), "paac_set_managed_weights")
+
     def grad_stats(self, clip_norm, clip_mode):
         """Gradient summaries of the last clip_rmsprop (actor_learner.py:85-87, logger_utils.py:23-33): dict with
         mean / stddev / max / min of the raw and of the clipped flat gradient, and global_norm.  Synchronises."""

@@ -72,6 +72,7 @@ class Network(object):
         self.output = None
         self.layout = None
         self.params = None
+        self.weights_changed = None      # callback(): the flat parameter buffer was rewritten from the host side
 
     # -- parameters --------------------------------------------------------------------------------
     def _allocate(self):
@@ -94,6 +95,8 @@ class Network(object):
                 raise ValueError("%s: shape %s, expected %s" % (t["name"], a.shape, t["shape"]))
             host[t["offset"]:t["offset"] + t["size"]] = a.reshape(-1)
         self.params.copy_(torch.from_numpy(host))
+        if self.weights_changed is not None:
+            self.weights_changed()
 
     def get_parameters(self, flat=None):
         host = (self.params if flat is None else flat).detach().cpu().numpy()

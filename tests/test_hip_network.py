@@ -348,3 +348,45 @@ def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
         scale = max(np.abs(want).max(), 1e-3 * gn_ref)
         assert err / scale < 1e-4, "%s: max abs err %g (scale %g)" % (name, err, scale)
     ctx.close()
+
+
+@pytest.mark.parametrize("regions", [4, 2, 1])
+@pytest.mark.parametrize("B,A", [(5, 4), (33, 6)])
+def test_conv_tower_variants(regions, B, A):
+    """csrc/tower.h: the fused conv1->conv2->conv3 launch in each of its region layouts (4 overlapping 4x4 regions, 2
+    halves, one workgroup per sample) against the float64 oracle -- conv1 / conv2 / conv3 activations, logits, values --
+    and against the unfused per-layer kernels (PAAC_TOWER=0 is the same arithmetic in a different summation order)."""
+    from paac_amd import _lib, hip_ops
+    params, states, idx, y, adv = make_case("NATURE", A, B, seed=3)
+    ctx = hip_ops.Context(ARCH_ID["NATURE"], A, max_batch=B)
+    for cls in (0, 1, 2):
+        _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, 11, cls, regions, 0, -1), "set_tuning")
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    logits = torch.zeros((B, A), device="cuda")
+    values = torch.zeros((B,), device="cuda")
+    ctx.forward(p, s, logits=logits, values=values)
+    torch.cuda.synchronize()
+    ref = onet.forward(params, states, "NATURE", dtype=np.float64, keep=True)
+    for i in (1, 2, 3):
+        got = ctx.debug_activation(i, B).cpu().numpy()
+        want = ref["cache"]["a%d" % i].reshape(-1)
+        assert got.shape == want.shape
+        err = np.abs(got - want).max()
+        assert err < 2e-5, "regions=%d conv%d: max abs err %g" % (regions, i, err)
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
+    # managed mode: the acting forward keeps only conv3's output; weights come from an explicit pack
+    ctx.set_managed_weights(True)
+    ctx.pack_weights(p)
+    logits2 = torch.zeros((B, A), device="cuda")
+    ctx.forward(p, s, logits=logits2)
+    assert torch.equal(logits, logits2)
+    # a stale pack is really used in managed mode (the contract: the owner of the writes re-packs) ...
+    p2 = p * 1.5
+    ctx.forward(p2, s, logits=logits2)
+    ctx.pack_weights(p2)
+    logits3 = torch.zeros((B, A), device="cuda")
+    ctx.forward(p2, s, logits=logits3)
+    assert not torch.equal(logits2, logits3)
+    ctx.close()
