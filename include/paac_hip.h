@@ -98,6 +98,20 @@ int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uin
 int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* values,
                        paac_stream_t stream);
 
+/* One whole acting step of the device-resident loop in three launches (paac.py:104-127 for N <= 64 environments with
+ * the reference's numpy sampler): policy forward on `states` (conv tower, fc with the head contractions in its epilogue),
+ * then ONE launch that finishes the heads (bias, softmax; probabilities and values also written to probs_out [N,A] /
+ * values_out [N]), samples the actions exactly like paac_sample_mt (np.random.multinomial(1, p - epsneg) per
+ * environment on the MT19937 state, advanced in place) and steps the synthetic environments like paac_synth_step
+ * (stack_out = shifted stacks with the new frame; rewards / masks / episode bookkeeping).
+ * Requires N <= PAAC_ACT_STEP_MAX_ENVS and N*(A-1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS. */
+#define PAAC_ACT_STEP_MAX_ENVS 64
+int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
+                     int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
+                     uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
+                     float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
+                     paac_stream_t stream);
+
 /* Conv-weight packing.  The Nature conv layers run as one fused launch that reads the conv weights pre-split into bf16
  * planes (an internal copy owned by the ctx).  By default every paac_forward* / paac_train_forward / paac_loss_backward
  * call refreshes that copy from `params` first (one small extra launch), so a caller may change `params` at any time.

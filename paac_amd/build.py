@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpaac_hip.so")
 SOURCES = ["api.hip", "net_fwd.hip", "net_bwd.hip", "misc.hip"]
-HEADERS = ["common.h", "dmm.h", "heads.h", "net_common.h", "synth_dev.h", os.path.join("..", "..", "include", "paac_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "paac_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 

@@ -137,7 +137,8 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
     Workspace& W = c->ws[w];
     for (int i = 0; i < c->spec.nconv; ++i) {
       const ConvSpec& cs = c->spec.conv[i];
-      PAAC_CHECK_HIP(hipMalloc(&W.act[i], (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float)));
+      // rows rounded up to 16: the packed conv3 -> fc hand-off (tower.h / fc_heads.h) addresses whole 16-row tiles
+      PAAC_CHECK_HIP(hipMalloc(&W.act[i], (size_t)((B + 15) / 16 * 16) * cs.oh * cs.ow * cs.cout * sizeof(float)));
     }
     PAAC_CHECK_HIP(hipMalloc(&W.fc_slab, (size_t)c->fc_splits_max * B * c->spec.fc * sizeof(float)));
     PAAC_CHECK_HIP(hipMalloc(&W.h, (size_t)B * c->spec.fc * sizeof(float)));
@@ -160,6 +161,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
     c->managed_weights = 0;
     c->tower_pack = nullptr;
     if (c->tower_on) PAAC_CHECK_HIP(hipMalloc(&c->tower_pack, tower_pack_bytes()));
+    PAAC_CHECK_HIP(hipMalloc(&c->fc_pack, (size_t)c->spec.flat * c->spec.fc * sizeof(float)));
   }
   c->ev_start = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
   c->ev_stop = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
@@ -191,6 +193,7 @@ int paac_destroy(paac_ctx* c) {
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (c->tower_pack) (void)hipFree(c->tower_pack);
+  if (c->fc_pack) (void)hipFree(c->fc_pack);
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
     if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
     if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -265,6 +268,31 @@ int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uin
   const int rc = launch_forward_sample_step(ctx, params, states, batch, probs, values, seed, step_base_dev, step_offset,
                                             env_offset, actions, env_seed, terminal_threshold, stack_out, rewards_out,
                                             masks_out, ep_reward, ep_len, finished, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
+                     int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
+                     uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
+                     float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
+                     paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states && mt_state && actions && probs_out && values_out && stack_out && rewards_out &&
+               masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS,
+               "paac_act_step_mt: batch %d outside (0, min(max_batch=%d, %d)]", batch, ctx->max_batch, PAAC_ACT_STEP_MAX_ENVS);
+  PAAC_REQUIRE((int64_t)batch * (ctx->cfg.num_actions - 1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS,
+               "paac_act_step_mt: N*(A-1) = %ld exceeds %d (use paac_forward + paac_sample_mt + paac_synth_step)",
+               (long)batch * (ctx->cfg.num_actions - 1), PAAC_FUSED_SAMPLE_MAX_DRAWS);
+  PAAC_REQUIRE(states != stack_out, "paac_act_step_mt: the step cannot shift the stacks in place");
+  const float *partial, *ba, *bc;
+  int ntiles;
+  int rc = launch_forward_trunk(ctx, params, states, batch, &partial, &ntiles, &ba, &bc, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = launch_sample_env_step_heads(partial, ntiles, ba, bc, probs_out, values_out, ctx->cfg.num_actions, mt_state, actions,
+                                    env_seed, env_offset, batch, terminal_threshold, step_base_dev, step_offset, states,
+                                    stack_out, rewards_out, masks_out, ep_reward, ep_len, finished, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;

@@ -99,6 +99,7 @@ struct paac_ctx {
   int fc_splits_max;
   // conv tower (csrc/tower.h, Nature only): conv weights pre-split into bf16 planes in MFMA operand order
   void* tower_pack;      // kTowerPackVecs x 16 bytes, nullptr when the tower is off
+  void* fc_pack;         // fc weights in fc_heads_kernel's fragment order (flat * H floats)
   int tower_on;          // PAAC_TOWER (default 1)
   int managed_weights;   // paac_set_managed_weights: 1 = the caller keeps tower_pack current (paac_clip_rmsprop / paac_pack_weights
                          // re-pack) and acting forwards keep no conv1 / conv2 activations; 0 = every forward re-packs first
@@ -166,6 +167,13 @@ int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t
                                uint8_t* stack_out, float* rewards, float* masks, float* ep_reward, int32_t* ep_len,
                                void* finished, hipStream_t s);
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s);
+int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, const float** partial,
+                         int* ntiles, const float** ba, const float** bc, hipStream_t s);
+int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,
+                                 float* values_out, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
+                                 uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
+                                 const uint8_t* stack_in, uint8_t* stack_out, float* rewards, float* masks,
+                                 float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s);
 

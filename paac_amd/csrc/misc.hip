@@ -2,6 +2,7 @@
 // frame preprocessing / stacking, device-resident synthetic environments, clip + RMSProp.
 #include "common.h"
 #include "synth_dev.h"
+#include "fc_heads.h"
 
 namespace paac {
 
@@ -218,11 +219,14 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
   }
 }
 
+// probs_lds (LDSPATH only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
+// stw_pre (with probs_lds): the caller requested the 625 state words (3 per thread, clamped index) before producing them.
 template <bool LDSPATH>
 __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
                                                double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
-                                               int32_t* __restrict__ actions, int32_t* act_lds) {
+                                               int32_t* __restrict__ actions, int32_t* act_lds,
+                                               const float* probs_lds = nullptr, const uint32_t* stw_pre = nullptr) {
   MISC_STAMP(0);
   __shared__ double pj_s[LDSPATH ? MT_LDS_D : 1];
   __shared__ double u_s[LDSPATH ? MT_LDS_D : 1];
@@ -245,25 +249,29 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     uint32_t stw[3];
     float prw[8];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) stw[k] = mt_state[min(tid + k * 256, 624)];
+    for (int k = 0; k < 3; ++k) stw[k] = stw_pre ? stw_pre[k] : mt_state[min(tid + k * 256, 624)];
+    if (!probs_lds) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) prw[k] = probs[min(tid + k * 256, N * A - 1)];
+      for (int k = 0; k < 8; ++k) prw[k] = probs[min(tid + k * 256, N * A - 1)];
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int idx = tid + k * 256;
       if (idx < 624) blocks[idx] = stw[k];
       if (idx == 624) pos_s = stw[k];
     }
+    if (!probs_lds) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (tid + k * 256 < N * A) probs_s[tid + k * 256] = prw[k];
+      for (int k = 0; k < 8; ++k)
+        if (tid + k * 256 < N * A) probs_s[tid + k * 256] = prw[k];
+    }
     __syncthreads();
     pos = pos_s;
   } else {
     pos = mt_state[624];
   }
   MISC_STAMP(1);
-  const float* pr = LDSPATH ? probs_s : probs;
+  const float* pr = LDSPATH ? (probs_lds ? probs_lds : probs_s) : probs;
   const int nblk = (int)((pos + 2u * (uint32_t)D) / 624u) + 1;
   // phase 1: conditional probabilities p_j / remaining_j, one (env, category) per thread: the running
   // `remaining` is rebuilt with the reference's sequential fp64 subtraction order (cheap), so that only ONE fp64
@@ -563,6 +571,45 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
   synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out);
 }
 
+// The same launch with the heads finish in front of the sampler: workgroup 0 sums the fc kernel's per-tile head partials
+// (csrc/fc_heads.h), adds the biases, takes the softmax -- probabilities straight into LDS for the sampler (and to HBM for
+// the learner's records) -- then samples and does the bookkeeping.  One launch per step for heads + sampler + env step.
+__global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __restrict__ partial, int ntiles,
+                                                               const float* __restrict__ ba, const float* __restrict__ bc,
+                                                               float* __restrict__ probs_out, float* __restrict__ values_out,
+                                                               int A, uint32_t* __restrict__ mt_state,
+                                                               int32_t* __restrict__ actions, uint64_t seed,
+                                                               uint32_t env_offset, int N, uint32_t thresh,
+                                                               const uint64_t* __restrict__ step_base, uint64_t step_off,
+                                                               const uint32_t* __restrict__ stack_in,
+                                                               uint32_t* __restrict__ stack_out, float* rewards_out,
+                                                               float* masks_out, float* ep_reward, int32_t* ep_len,
+                                                               FinishedRing* fin) {
+  const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
+  if (blockIdx.x == 0) {
+    __shared__ int32_t act_s[kFcHeadsMaxRows];
+    __shared__ float lg_s[kFcHeadsMaxRows * 33];
+    __shared__ float probs_sh[kFcHeadsMaxRows * 32];
+    // nothing below depends on these: request them before the head sums
+    uint32_t stw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) stw[k] = mt_state[min((int)threadIdx.x + k * 256, 624)];
+    const int e0 = threadIdx.x < N ? threadIdx.x : 0;
+    const float ep_reward0 = ep_reward[e0];
+    const int32_t ep_len0 = ep_len[e0];
+    heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,
+                        nullptr);
+    sample_mt_body<true>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
+    __syncthreads();
+    for (int e = threadIdx.x; e < N; e += 256) {
+      const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
+      synth_bookkeep_with(key, e, act_s[e], thresh, ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
+    }
+    return;
+  }
+  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out);
+}
+
 // Path B, stage 1: generate the two raw 210x160 gray frames of this step + bookkeeping.
 // grid (N, 8), 256 threads; 16800 dwords per env.
 __global__ __launch_bounds__(256) void synth_raw_kernel(uint64_t seed, uint32_t env_offset, int N,
@@ -747,6 +794,18 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
     }
   }
 #undef PAAC_RMS
+}
+
+int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,
+                                 float* values_out, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
+                                 uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
+                                 const uint8_t* stack_in, uint8_t* stack_out, float* rewards, float* masks,
+                                 float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s) {
+  ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, s);
+  launch_k(synth_step_a_mth_kernel, dim3(1 + N * PRE_BANDS), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
+           values_out, A, mt_state, actions, seed, env_offset, N, thresh, step_base, step_off, (const uint32_t*)stack_in,
+           (uint32_t*)stack_out, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished);
+  return 0;
 }
 
 }  // namespace paac

@@ -5,6 +5,7 @@
 // (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
 #include "net_common.h"
 #include "tower.h"
+#include "fc_heads.h"
 
 namespace paac {
 
@@ -89,8 +90,18 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
 size_t tower_pack_bytes() { return (size_t)kTowerPackVecs * sizeof(bf16x8); }
 
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
-  if (!ctx->tower_on) return 0;
   const paac_layout& L = ctx->layout;
+  {   // fc weights in fragment order for the small-batch fc + heads kernel (fc_heads.h)
+    const float* wf = params + L.offset[2 * ctx->spec.nconv];
+    f32x4* out = reinterpret_cast<f32x4*>(ctx->fc_pack);
+    if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+      launch_k(pack_fc_kernel<NatureNet::FLAT, NatureNet::H>, dim3((NatureNet::FLAT / 16) * (NatureNet::H / 16) * 64 / 256),
+               dim3(256), s, PROF_NONE, wf, out);
+    else
+      launch_k(pack_fc_kernel<NipsNet::FLAT, NipsNet::H>, dim3((NipsNet::FLAT / 16) * (NipsNet::H / 16) * 64 / 256), dim3(256),
+               s, PROF_NONE, wf, out);
+  }
+  if (!ctx->tower_on) return 0;
   constexpr int threads = (8 * 2 + 16 * 4 + 18 * 4) * 64;
   launch_k(pack_tower_kernel, dim3((threads + 255) / 256), dim3(256), s, PROF_NONE, params + L.offset[0], params + L.offset[2],
            params + L.offset[4], reinterpret_cast<bf16x8*>(ctx->tower_pack));
@@ -103,8 +114,9 @@ static void launch_tower_variant(const TowerArgs& a, hipStream_t s) {
 }
 
 // keep = also write the fp32 conv1 / conv2 activations (the backward pass and the debug read-back need them)
+// packed3: conv3's output goes out in fc_heads_kernel's A-fragment order (acting rows that nothing else reads)
 static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const uint8_t* states, int batch, bool keep,
-                         hipStream_t s) {
+                         bool packed3, hipStream_t s) {
   const paac_layout& L = ctx->layout;
   TowerArgs a;
   a.states = states;
@@ -119,6 +131,7 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
   a.act2 = W.act[1];
   a.act3 = W.act[2];
   a.batch = batch;
+  a.act3_packed = packed3 ? 1 : 0;
 #ifdef PAAC_DMM_STAMPS
   a.stamps = g_tower_stamps;
 #endif
@@ -140,7 +153,8 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
 
 template <class NT>
 static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
-                        float* probs, float* values, const PhiloxArgs& ph, const SynthStepArgs& st, hipStream_t s) {
+                        float* probs, float* values, const PhiloxArgs& ph, const SynthStepArgs& st, hipStream_t s,
+                        bool defer_heads = false) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[wsi];
   ctx->last_ws = wsi;
@@ -166,10 +180,15 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
 
   bool tower = false;
   if constexpr (NT::NCONV == 3) tower = ctx->tower_on != 0;
+  const bool keep_acts = wsi == 1 || !ctx->managed_weights;          // fp32 conv activations / h kept for backward and read-back
+  const bool small_tail = batch <= kFcHeadsMaxRows && !ph.enabled && !st.enabled;   // fc + head partials kernel (fc_heads.h)
+  // conv3 -> fc hand-off in the fc kernel's fragment order: rows are padded to 16 inside the activation buffer (max_batch
+  // is rounded up at allocation)
+  const bool packed3 = tower && small_tail && !keep_acts;
+  if (!ctx->managed_weights && (tower || batch <= kFcHeadsMaxRows)) launch_pack_weights(ctx, params, s);
   if (tower) {
-    if (!ctx->managed_weights) launch_pack_weights(ctx, params, s);
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
-    launch_tower(ctx, W, params, states, batch, wsi == 1 || !ctx->managed_weights, s);
+    launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s);
   }
   if (!tower) {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
@@ -190,6 +209,34 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
     launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);
     last = W.act[2];
+  }
+  // Small acting / evaluation batches: fc with the head contractions folded into its epilogue (fc_heads.h), then the
+  // head finish -- as its own one-workgroup launch here, or (defer_heads) inside the caller's sampler launch.
+  if (small_tail) {
+    constexpr int NTILES = NT::H / 16;
+    float* partial = W.fc_slab;      // [NTILES][batch][A + 1]: fits the split-K slab buffer
+    const bool keep_h = keep_acts;
+    {
+      ProfScope ps(ctx, F_FC_FWD, batch, s);
+      constexpr int NW = (NT::FLAT / 16) % 7 == 0 ? 7 : 9;      // waves per workgroup: divides the K groups evenly
+      if (packed3)
+        launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, true>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,
+                 last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, (float*)nullptr);
+      else
+        launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, false>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,
+                 last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial,
+                 keep_h ? W.h : (float*)nullptr);
+    }
+    if (!defer_heads) {
+      ProfScope ps(ctx, F_HEADS_FWD, batch, s);
+      launch_k(heads_finish_kernel, dim3(1), dim3(256), s, PROF_WHOLE, (const float*)partial, NTILES, batch, A, ba, bc,
+               W.logits, W.probs, W.values, logits, probs, values);
+    }
+    return 0;
+  }
+  if (defer_heads) {
+    set_error("forward: deferred heads need batch <= %d", kFcHeadsMaxRows);
+    return -1;
   }
   int splits = 1;
   {
@@ -218,6 +265,24 @@ int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* st
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
   return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
+}
+
+// Acting trunk up to the per-tile head partials (fc_heads.h); the caller's sampler launch finishes the heads.
+int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, const float** partial,
+                         int* ntiles, const float** ba, const float** bc, hipStream_t s) {
+  PhiloxArgs ph;
+  memset(&ph, 0, sizeof(ph));
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
+  const paac_layout& L = ctx->layout;
+  const int nt = L.num_tensors;
+  *ba = params + L.offset[nt - 3];
+  *bc = params + L.offset[nt - 1];
+  *partial = ctx->ws[0].fc_slab;
+  *ntiles = ctx->spec.fc / 16;
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
 }
 
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,

@@ -40,6 +40,8 @@ struct TowerArgs {
   float* act1;                             // [B,20,20,32] fp32 (WRITE_ALL only)
   float* act2;                             // [B,9,9,64]   fp32 (WRITE_ALL only)
   float* act3;                             // [B,7,7,64]   fp32 = the fc layer's input rows (flatten keeps HWC, networks.py:6-9)
+  int act3_packed;                         // 1: act3 is written in fc_heads_kernel's A-fragment order instead:
+                                           //    [row tile b/16][K group k/16][(k%16)/4 * 16 + b%16][k%4], k = (y*7 + x)*64 + c
   int batch;
 #ifdef PAAC_DMM_STAMPS
   unsigned long long* stamps;               // diagnostic build only: 12 x u64 per wave
@@ -114,11 +116,18 @@ struct TowerGeom {
   static constexpr bool KSPLIT2 = (PT2 % 2) != 0, KSPLIT3 = (PT3 % 2) != 0;
   static constexpr int NT1 = (PT1 + 3) / 4;                            // conv1: pixel tiles per wave (4 pixel groups x 2 channel tiles)
   static constexpr int NT2 = KSPLIT2 ? PT2 : PT2 / 2, NT3 = KSPLIT3 ? PT3 : PT3 / 2;
+  // weight prefetch depth per layer (k-steps ahead); a depth >= the k-step count loads every fragment up front
+  static constexpr int PF1 = 8, PF2 = KSPLIT2 ? 8 : 6, PF3 = KSPLIT3 ? 9 : 6;
   static constexpr int IN_BYTES = RIH * RIW * 8;
   static constexpr int SCR2 = KSPLIT2 ? 4 * NT2 * 1024 : 0;            // K-split partials of 4 waves, f32x4 per lane and tile
   static constexpr int FRONT = (IN_BYTES > 3 * PL2 + SCR2) ? IN_BYTES : 3 * PL2 + SCR2;   // input image, later conv2 planes (+ partials)
   static constexpr int FRONT_AL = (FRONT + 15) / 16 * 16;
-  static constexpr int LDS_BYTES = FRONT_AL + 3 * PL1;
+  static constexpr int W1_BYTES = kTowerW1Vecs * 16;                    // conv1's packed weights: 48 KB
+  // conv1's pixel tiles are split over waves that share a channel tile, so each weight fragment would be fetched by four
+  // waves: where LDS has room the workgroup stages conv1's weights once (and then has the registers to request ALL of
+  // conv2's weight fragments at kernel start)
+  static constexpr bool W1_LDS = FRONT_AL + 3 * PL1 + W1_BYTES <= 160 * 1024;
+  static constexpr int LDS_BYTES = FRONT_AL + 3 * PL1 + (W1_LDS ? W1_BYTES : 0);
   static_assert(RIW % 4 == 0, "input rows are staged 4 pixels (16 bytes) at a time");
   static_assert(!KSPLIT3 || 4 * NT3 * 1024 <= 3 * PL1, "conv3 K-split partials reuse the conv1 planes");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -128,49 +137,84 @@ __device__ __forceinline__ f32x4 mfma_bf16(const bf16x8 a, const bf16x8 b, const
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// One wave: acc[t] += sum over NS k-steps of  A(weights, global k-step SG(i)) x B(patch fragments of tile t).
-//   wl     : packed weights of the layer + lane
-//   unit0  : SG(i) * CT + ct is the (k-step, channel-tile) unit; unit = (sg_mul * i + sg_add) * CT + ct
+// One wave: acc[t] += sum over NS k-steps of  A(weights, global k-step sg_mul * i + sg_add) x B(patch fragments of tile t).
+//   wl     : packed weights of the layer + lane; unit (k-step sg, channel tile ct) = 192 vectors (3 planes x 64 lanes)
 //   KOFF   : functor, KOFF::at(i) = byte offset of k-step i inside the LDS image (compile-time after unrolling)
 //   BP     : B planes: 1 (exact bf16 operand) or 3 (hi, mid, lo at BPL bytes apart)
-template <int NS, int NT, int CT, int BP, int BPL, int PF, class KOFF>
-__device__ __forceinline__ void wave_gemm(const bf16x8* __restrict__ wl, const int ct, const int sg_mul, const int sg_add,
-                                          const char* __restrict__ lds_b, const unsigned (&bb)[NT], f32x4 (&acc)[NT]) {
-  bf16x8 a[PF + 1][3];
-  auto load_a = [&](const int slot, const int i) {
+//   PF     : weight fragments are requested PF k-steps ahead of their MFMAs (PF >= NS: all of them up front)
+// The weight prefetch is split off (prologue) so a phase can request its first fragments BEFORE the barrier that ends the
+// previous phase; patch fragments of step i + 1 are read from LDS before the MFMAs of step i.  sched_barrier pins that
+// order: left alone, the machine scheduler sinks every load to just before its first use (s_waitcnt vmcnt(0) per step).
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <int NS, int NT, int CT, int BP, int BPL, int PF_, class KOFF>
+struct WaveGemm {
+  static constexpr int PF = PF_ < NS ? PF_ : NS;
+  static constexpr int RING = PF < NS ? PF + 1 : NS;
+  bf16x8 a[RING][3];
+  const bf16x8* wl;        // global (or LDS, generic address space: the compiler sees which from the caller's pointer)
+  int ct, sg_mul, sg_add;
+
+  __device__ __forceinline__ void set(const bf16x8* wl_, const int ct_, const int sg_mul_, const int sg_add_) {
+    wl = wl_; ct = ct_; sg_mul = sg_mul_; sg_add = sg_add_;
+  }
+  __device__ __forceinline__ void load_a(const int slot, const int i) {
     const bf16x8* src = wl + (long)((sg_mul * i + sg_add) * CT + ct) * 192;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) a[slot][pl] = src[pl * 64];
-  };
+  }
+  // request the weight fragments of prefetch step j (0 <= j < PF); out-of-range j: nothing
+  __device__ __forceinline__ void prologue_step(const int j) {
+    if (j >= 0 && j < PF) load_a(j, j);
+  }
+  __device__ __forceinline__ void prologue(const bf16x8* wl_, const int ct_, const int sg_mul_, const int sg_add_) {
+    set(wl_, ct_, sg_mul_, sg_add_);
 #pragma unroll
-  for (int i = 0; i < PF && i < NS; ++i) load_a(i, i);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    if (i + PF < NS) load_a((i + PF) % (PF + 1), i + PF);
-    const int slot = i % (PF + 1);
+    for (int i = 0; i < PF; ++i) load_a(i, i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void read_b(bf16x8 (&b)[NT][BP], const char* lds_b, const unsigned (&bb)[NT], const int i) {
     const int ko = KOFF::at(i);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const char* bp = lds_b + bb[t] + ko;
-      if constexpr (BP == 1) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp);
-        acc[t] = mfma_bf16(a[slot][2], b, acc[t]);   // smallest terms first
-        acc[t] = mfma_bf16(a[slot][1], b, acc[t]);
-        acc[t] = mfma_bf16(a[slot][0], b, acc[t]);
-      } else {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + BPL);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * BPL);
-        acc[t] = mfma_bf16(a[slot][2], bh, acc[t]);
-        acc[t] = mfma_bf16(a[slot][1], bm, acc[t]);
-        acc[t] = mfma_bf16(a[slot][0], bl, acc[t]);
-        acc[t] = mfma_bf16(a[slot][1], bh, acc[t]);
-        acc[t] = mfma_bf16(a[slot][0], bm, acc[t]);
-        acc[t] = mfma_bf16(a[slot][0], bh, acc[t]);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int pl = 0; pl < BP; ++pl) b[t][pl] = *reinterpret_cast<const bf16x8*>(lds_b + bb[t] + ko + pl * BPL);
+  }
+  // hook(i): extra requests issued with step i's own (the NEXT layer's weight fragments, into the registers this layer's
+  // consumed fragments free)
+  template <class Hook = NoHook>
+  __device__ __forceinline__ void run(const char* __restrict__ lds_b, const unsigned (&bb)[NT], f32x4 (&acc)[NT],
+                                      Hook hook = Hook()) {
+    bf16x8 b[2][NT][BP];
+    read_b(b[0], lds_b, bb, 0);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i + PF < NS) load_a((i + PF) % RING, i + PF);
+      hook(i);
+      if (i + 1 < NS) read_b(b[(i + 1) & 1], lds_b, bb, i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int slot = i % RING;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (BP == 1) {
+          acc[t] = mfma_bf16(a[slot][2], b[i & 1][t][0], acc[t]);   // smallest terms first
+          acc[t] = mfma_bf16(a[slot][1], b[i & 1][t][0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][0], acc[t]);
+        } else {
+          acc[t] = mfma_bf16(a[slot][2], b[i & 1][t][0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][1], b[i & 1][t][1], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][2], acc[t]);
+          acc[t] = mfma_bf16(a[slot][1], b[i & 1][t][0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][1], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][0], acc[t]);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-}
+};
 
 // 4 fp32 (consecutive channels of one pixel) -> (hi, mid, lo) bf16 x 4 -> one 8-byte LDS store per plane
 template <int PLANE_STRIDE>
@@ -216,6 +260,7 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
   char* const lds_s2 = lds + 3 * G::PL2;          // conv2 K-split partials                    (phase 2)
   char* const lds_a1 = lds + G::FRONT_AL;         // conv1 planes [3][P1][S1]                  (phase 1-2)
   char* const lds_s3 = lds_a1;                    // conv3 K-split partials                    (phase 3)
+  char* const lds_w1 = lds_a1 + 3 * G::PL1;       // conv1's packed weights (W1_LDS)             (phase 0-1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -228,6 +273,10 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
 
   TOWER_STAMP(0);
   TOWER_STAMP(1);
+  // conv1's weights: from LDS (staged below) with a short read-ahead, or straight from global, all 8 k-steps requested now
+  WaveGemm<8, G::NT1, 2, 1, 0, G::W1_LDS ? 2 : G::PF1, Koff1<G>> g1;
+  WaveGemm<G::KSPLIT2 ? 8 : 16, G::NT2, 4, 3, G::PL1, G::PF2, Koff2<G>> g2;
+
   // ---- phase 0: input region -> LDS as bf16 (a byte is exact in bf16) ---------------------------------------------
   {
     constexpr int VROW = G::RIW / 4, NV = G::RIH * VROW, ITERS = (NV + 511) / 512;
@@ -238,6 +287,16 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
       const int i = tid + it * 512;
       const int r = i / VROW, c4 = i - r * VROW;
       if (i < NV) v[it] = *reinterpret_cast<const uint4*>(src + (r * 84 + 4 * c4) * 4);
+    }
+    // behind the image (a wave's loads return in order, and the eight waves' requests share one queue: anything requested
+    // ahead of the image delays the staging of every wave): conv1's packed weights, for LDS or as this wave's fragments
+    constexpr int W1V = G::W1_LDS ? kTowerW1Vecs / 512 : 1;
+    bf16x8 w1v[W1V];
+    if constexpr (G::W1_LDS) {
+#pragma unroll
+      for (int it = 0; it < W1V; ++it) w1v[it] = p.w1p[tid + it * 512];
+    } else {
+      g1.prologue(p.w1p + lane, wave & 1, 1, 0);
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -257,6 +316,10 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
         dst[0] = o[0];
         dst[1] = o[1];
       }
+    }
+    if constexpr (G::W1_LDS) {
+#pragma unroll
+      for (int it = 0; it < W1V; ++it) reinterpret_cast<bf16x8*>(lds_w1)[tid + it * 512] = w1v[it];
     }
   }
   TOWER_STAMP(2);
@@ -282,8 +345,15 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
 #pragma unroll
     for (int j = 0; j < G::NT1; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + 16 * ct + 4 * kq);
-    wave_gemm<8, G::NT1, 2, 1, 0, 3, Koff1<G>>(p.w1p + lane, ct, 1, 0, lds_in, bb, acc);
+    if constexpr (G::W1_LDS) {
+      // conv2's weight fragments stream in while conv1 computes (conv1's own weights come from LDS: the registers are free)
+      g2.prologue(p.w2p + lane, wave & 3, 1, G::KSPLIT2 ? 8 * (wave >> 2) : 0);
+      g1.prologue(reinterpret_cast<const bf16x8*>(lds_w1) + lane, ct, 1, 0);
+    }
+    g1.run(lds_in, bb, acc);
     TOWER_STAMP(4);
+    if constexpr (!G::W1_LDS)   // conv2's first weights: ahead of the epilogue + barrier (W1_LDS: requested before conv1's GEMM)
+      g2.prologue(p.w2p + lane, wave & 3, 1, G::KSPLIT2 ? 8 * (wave >> 2) : 0);
 #pragma unroll
     for (int j = 0; j < G::NT1; ++j) {
       if (pix[j] < 0) continue;
@@ -301,6 +371,8 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
   __syncthreads();
   TOWER_STAMP(6);
 
+  WaveGemm<9, G::NT3, 4, 3, G::PL2, G::PF3, Koff3Half<G>> g3h;     // only the one matching KSPLIT3 is used
+  WaveGemm<18, G::NT3, 4, 3, G::PL2, G::PF3, Koff3Full<G>> g3f;
   // ---- phase 2: conv2 (K = 512 = 16 taps x 32 channels) ---------------------------------------------------------------
   {
     const int ct = wave & 3, half = wave >> 2;
@@ -321,36 +393,49 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
 #pragma unroll
     for (int j = 0; j < G::NT2; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b2 + 16 * ct + 4 * kq);
-    if constexpr (G::KSPLIT2) {
-      wave_gemm<8, G::NT2, 4, 3, G::PL1, 3, Koff2<G>>(p.w2p + lane, ct, 1, 8 * half, lds_a1, bb, acc);
-      TOWER_STAMP(7);
-      f32x4* scr = reinterpret_cast<f32x4*>(lds_s2);
-      if (half == 1) {
+    // conv3's weight fragments are requested while conv2 computes: step j of its prefetch window rides with conv2's k-step
+    // j + (NS2 - PF3), into the registers conv2's consumed fragments have freed (the window's head first when it is longer)
+    constexpr int NS2 = G::KSPLIT2 ? 8 : 16;
+    if constexpr (G::KSPLIT3) {
+      constexpr int LEAD = decltype(g3h)::PF - NS2;
+      g3h.set(p.w3p + lane, ct, 2, half);
 #pragma unroll
-        for (int j = 0; j < G::NT2; ++j) scr[(ct * G::NT2 + j) * 64 + lane] = acc[j];
-      }
-      __syncthreads();      // also: every wave is done reading the input image, whose space the conv2 planes take over
-      if (half == 0) {
-#pragma unroll
-        for (int j = 0; j < G::NT2; ++j) acc[j] += scr[(ct * G::NT2 + j) * 64 + lane];
-      }
+      for (int j = 0; j < LEAD; ++j) g3h.prologue_step(j);
+      g2.run(lds_a1, bb, acc, [&](const int i) { g3h.prologue_step(i + LEAD); });
     } else {
-      wave_gemm<16, G::NT2, 4, 3, G::PL1, 3, Koff2<G>>(p.w2p + lane, ct, 1, 0, lds_a1, bb, acc);
-      TOWER_STAMP(7);
+      constexpr int LEAD = decltype(g3f)::PF - NS2;
+      g3f.set(p.w3p + lane, ct, 1, 0);
+#pragma unroll
+      for (int j = 0; j < LEAD; ++j) g3f.prologue_step(j);
+      g2.run(lds_a1, bb, acc, [&](const int i) { g3f.prologue_step(i + LEAD); });
     }
-    if (!G::KSPLIT2 || half == 0) {
+    TOWER_STAMP(7);
+    // K-split: the two waves of a channel tile hold partial sums of the same tiles.  Each finishes part of them (half 0 the
+    // first OWN0 tiles, half 1 the rest): it parks the partials of the tiles it does NOT own in LDS, and after the barrier adds
+    // its partner's to its own (a + b is the same float either way round).
+    constexpr int OWN0 = G::KSPLIT2 ? (G::NT2 + 1) / 2 : G::NT2;
+    const int j_lo = (G::KSPLIT2 && half == 1) ? OWN0 : 0, j_hi = (G::KSPLIT2 && half == 0) ? OWN0 : G::NT2;
+    if constexpr (G::KSPLIT2) {
+      f32x4* scr = reinterpret_cast<f32x4*>(lds_s2);
 #pragma unroll
-      for (int j = 0; j < G::NT2; ++j) {
-        if (pix[j] < 0) continue;
-        f32x4 v;
+      for (int j = 0; j < G::NT2; ++j)
+        if (j < j_lo || j >= j_hi) scr[(ct * G::NT2 + j) * 64 + lane] = acc[j];
+      __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[j][e] + bias[e], 0.f);
-        if constexpr (WRITE_ALL) {
-          const int y2 = pix[j] / G::R2W, x2 = pix[j] - y2 * G::R2W;
-          *reinterpret_cast<f32x4*>(p.act2 + ((size_t)(b * 9 + y3a + y2) * 9 + x3a + x2) * 64 + 16 * ct + 4 * kq) = v;
-        }
-        store_split4<G::PL2>(lds_a2 + pix[j] * G::S2 + (16 * ct + 4 * kq) * 2, v);
+      for (int j = 0; j < G::NT2; ++j)
+        if (j >= j_lo && j < j_hi) acc[j] += scr[(ct * G::NT2 + j) * 64 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < G::NT2; ++j) {
+      if (j < j_lo || j >= j_hi || pix[j] < 0) continue;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[j][e] + bias[e], 0.f);
+      if constexpr (WRITE_ALL) {
+        const int y2 = pix[j] / G::R2W, x2 = pix[j] - y2 * G::R2W;
+        *reinterpret_cast<f32x4*>(p.act2 + ((size_t)(b * 9 + y3a + y2) * 9 + x3a + x2) * 64 + 16 * ct + 4 * kq) = v;
       }
+      store_split4<G::PL2>(lds_a2 + pix[j] * G::S2 + (16 * ct + 4 * kq) * 2, v);
     }
   }
   __syncthreads();
@@ -375,9 +460,10 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
 #pragma unroll
     for (int j = 0; j < G::NT3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b3 + 16 * ct + 4 * kq);
+    if constexpr (G::KSPLIT3) g3h.run(lds_a2, bb, acc);
+    else g3f.run(lds_a2, bb, acc);
+    TOWER_STAMP(9);
     if constexpr (G::KSPLIT3) {
-      wave_gemm<9, G::NT3, 4, 3, G::PL2, 3, Koff3Half<G>>(p.w3p + lane, ct, 2, half, lds_a2, bb, acc);
-      TOWER_STAMP(9);
       f32x4* scr = reinterpret_cast<f32x4*>(lds_s3);      // the conv1 planes: dead since the barrier before this phase
       if (half == 1) {
 #pragma unroll
@@ -388,9 +474,6 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
 #pragma unroll
         for (int j = 0; j < G::NT3; ++j) acc[j] += scr[(ct * G::NT3 + j) * 64 + lane];
       }
-    } else {
-      wave_gemm<18, G::NT3, 4, 3, G::PL2, 3, Koff3Full<G>>(p.w3p + lane, ct, 1, 0, lds_a2, bb, acc);
-      TOWER_STAMP(9);
     }
     if (!G::KSPLIT3 || half == 0) {
       // overlapping regions: the second region along an axis starts at 7 - R3 and leaves the shared rows / columns to the first
@@ -403,7 +486,11 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[j][e] + bias[e], 0.f);
-        *reinterpret_cast<f32x4*>(p.act3 + ((size_t)(b * 7 + y3a + y3) * 7 + x3a + x3) * 64 + 16 * ct + 4 * kq) = v;
+        const int k0 = ((y3a + y3) * 7 + x3a + x3) * 64 + 16 * ct + 4 * kq;      // feature index of v[0] in the flattened row
+        if (p.act3_packed)
+          *reinterpret_cast<f32x4*>(p.act3 + ((((size_t)(b >> 4) * (3136 / 16) + (k0 >> 4)) * 64 + ((k0 >> 2) & 3) * 16 + (b & 15)) << 2)) = v;
+        else
+          *reinterpret_cast<f32x4*>(p.act3 + (size_t)b * 3136 + k0) = v;
       }
     }
   }

@@ -64,12 +64,16 @@ class Context(object):
             pass
 
     # -- network ---------------------------------------------------------------------------------
-    def forward(self, params, states, logits=None, probs=None, values=None):
+    def _check_states(self, states):
         B = states.shape[0]
         if tuple(states.shape[1:]) != OBS_SHAPE:
             raise ValueError("states must be [B,84,84,4] uint8, got %s" % (tuple(states.shape),))
         if not (0 < B <= self.max_batch):
             raise ValueError("batch %d outside (0, %d]" % (B, self.max_batch))
+        return B
+
+    def forward(self, params, states, logits=None, probs=None, values=None):
+        B = self._check_states(states)
         A = self.num_actions
         _lib.check(self.lib.paac_forward(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
                                          _ptr(states, torch.uint8, B * 28224, "states"), B,
@@ -157,6 +161,32 @@ class Context(object):
                                               float(eps), float(clip_norm), int(clip_mode), float(grad_scale),
                                               _ptr(gnorm_out, torch.float32, 1, "gnorm_out", True), _stream()),
                    "paac_clip_rmsprop")
+
+    def act_step_mt(self, params, states, mt_state, actions, probs_out, values_out, env_seed, env_offset,
+                    terminal_threshold, step_base_dev, step_offset, stack_out, rewards_out, masks_out, ep_reward, ep_len,
+                    finished=None):
+        """One acting step in three launches: policy forward, then heads finish + numpy-parity sampler + synthetic
+        environment step in one (include/paac_hip.h: paac_act_step_mt)."""
+        N, A = self._check_states(states), self.num_actions
+        if N > ACT_STEP_MAX_ENVS or N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
+            raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS, FUSED_SAMPLE_MAX_DRAWS))
+        if tuple(stack_out.shape) != (N,) + OBS_SHAPE:
+            raise ValueError("stack_out must be [%d,84,84,4], got %s" % (N, tuple(stack_out.shape)))
+        if states.data_ptr() == stack_out.data_ptr():
+            raise ValueError("the step cannot shift the stacks in place")
+        if finished is not None and finished.numel() * finished.element_size() < FINISHED_RING_BYTES:
+            raise ValueError("finished ring too small")
+        _lib.check(self.lib.paac_act_step_mt(
+            self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+            _ptr(states, torch.uint8, N * 28224, "states"), N, _ptr(mt_state, torch.int32, 625, "mt_state"),
+            _ptr(actions, torch.int32, N, "actions"), _ptr(probs_out, torch.float32, N * A, "probs_out"),
+            _ptr(values_out, torch.float32, N, "values_out"), int(env_seed), int(env_offset), int(terminal_threshold),
+            _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
+            _ptr(stack_out, torch.uint8, N * 28224, "stack_out"), _ptr(rewards_out, torch.float32, N, "rewards_out"),
+            _ptr(masks_out, torch.float32, N, "masks_out"), _ptr(ep_reward, torch.float32, N, "ep_reward"),
+            _ptr(ep_len, torch.int32, N, "ep_len"),
+            ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),
+            "paac_act_step_mt")
 
     def pack_weights(self, params):
         """Refresh the ctx's pre-split copy of the conv weights (include/paac_hip.h: paac_pack_weights)."""
@@ -335,6 +365,7 @@ def synth_step(seed, env_offset, actions, terminal_threshold, step_base_dev, ste
 
 
 FUSED_SAMPLE_MAX_DRAWS = 1024
+ACT_STEP_MAX_ENVS = 64
 
 
 def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_threshold, step_base_dev, step_offset,

@@ -98,7 +98,14 @@ class DeviceRollout(object):
         params = L.network.params
         st = [self.states[self._slot(parity, t)] for t in range(T + 1)]
         for t in range(T):
-            if self.sampler == "numpy" and self.raw is None and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS:
+            fused = self.sampler == "numpy" and self.raw is None and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS
+            if fused and N <= hip_ops.ACT_STEP_MAX_ENVS:
+                # the whole step in three launches: conv tower, fc + head partials, heads finish + sampler + env step
+                L.ctx.act_step_mt(params, st[t], self.mt_state, self.actions[t], self.probs, self.values[t],
+                                  self.env_spec["seed"], self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
+                                  st[t + 1], self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished)
+                continue
+            if fused:
                 # numpy-parity sampler and env step in one launch (the frame shift does not need the action)
                 L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
                 hip_ops.sample_mt_synth_step(self.probs, self.mt_state, self.actions[t], self.env_spec["seed"],

@@ -250,3 +250,64 @@ def test_synthetic_env_matches_host_spec(raw_frames):
     assert got == sorted((float(r), int(l)) for r, l in finished)
     assert np.array_equal(ep_r.cpu().numpy(), tot_r.astype(np.float32))
     assert np.array_equal(ep_l.cpu().numpy(), tot_l.astype(np.int32))
+
+
+@pytest.mark.parametrize("managed", [False, True])
+@pytest.mark.parametrize("arch,A,N", [("NATURE", 4, 32), ("NATURE", 6, 33), ("NIPS", 18, 16), ("NATURE", 18, 60)])
+def test_act_step_equals_separate_calls(arch, A, N, managed):
+    """paac_act_step_mt (forward with the head contractions in the fc epilogue, then heads finish + MT19937 sampler +
+    synthetic env step in ONE launch) == paac_forward + paac_sample_mt + paac_synth_step, bit for bit, over consecutive
+    steps (probabilities, values, actions, stream position, stacks, rewards, masks, episode bookkeeping)."""
+    from oracle import network as onet
+    from paac_amd import hip_ops
+    from paac_amd.synthetic import terminal_threshold
+    arch_id = {"NIPS": 0, "NATURE": 1}[arch]
+    ctx = hip_ops.Context(arch_id, A, max_batch=N)
+    host = onet.init_params(arch, A, np.random.RandomState(1), dtype=np.float32)
+    flat = np.zeros(ctx.layout["total"], dtype=np.float32)
+    for t in ctx.layout["tensors"]:
+        flat[t["offset"]:t["offset"] + t["size"]] = host[t["name"]].reshape(-1)
+    p = torch.from_numpy(flat).cuda()
+    if managed:       # the learner's mode: explicit weight packing, conv3 -> fc hand-off in fragment order, no kept activations
+        ctx.set_managed_weights(True)
+        ctx.pack_weights(p)
+    env_seed, off, thr = 5, 3, terminal_threshold(0.15)
+    rs = np.random.RandomState(77)
+
+    def fresh():
+        d = dict(s0=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 s1=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 act=torch.zeros(N, dtype=torch.int32, device="cuda"), probs=torch.zeros((N, A), device="cuda"),
+                 val=torch.zeros(N, device="cuda"), rew=torch.zeros(N, device="cuda"), msk=torch.zeros(N, device="cuda"),
+                 ep_r=torch.zeros(N, device="cuda"), ep_l=torch.zeros(N, dtype=torch.int32, device="cuda"),
+                 fin=torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device="cuda"),
+                 tick=torch.zeros(1, dtype=torch.int64, device="cuda"),
+                 mt=hip_ops.mt_state_from_numpy(rs.get_state(), "cuda"))
+        hip_ops.synth_reset(env_seed, off, d["s0"], None)
+        return d
+
+    a, b = fresh(), fresh()
+    scratch = hip_ops.sample_mt_scratch(N, A, "cuda")
+    for step in range(8):
+        ctx.act_step_mt(p, a["s0"], a["mt"], a["act"], a["probs"], a["val"], env_seed, off, thr, a["tick"], 0, a["s1"],
+                        a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"])
+        ctx.forward(p, b["s0"], probs=b["probs"], values=b["val"])
+        hip_ops.sample_mt(b["probs"], b["mt"], scratch, b["act"])
+        hip_ops.synth_step(env_seed, off, b["act"], thr, b["tick"], 0, b["s0"], b["s1"], b["rew"], b["msk"], b["ep_r"],
+                           b["ep_l"], b["fin"])
+        torch.cuda.synchronize()
+        for k in ("probs", "val", "act", "mt", "rew", "msk", "ep_r", "ep_l", "s1"):
+            assert torch.equal(a[k], b[k]), "step %d: %s differs" % (step, k)
+        fa, fb = a["fin"].cpu().numpy(), b["fin"].cpu().numpy()
+        n = int(fa[0])
+        assert fa[0] == fb[0] and sorted(fa[2:2 + n].tolist()) == sorted(fb[2:2 + n].tolist())
+        for d in (a, b):
+            hip_ops.counter_add(d["tick"], 1)
+            d["s0"], d["s1"] = d["s1"], d["s0"]
+    assert int(a["fin"][0]) > 0
+    # the probabilities are the oracle's (float64 restatement) within the forward tolerance
+    states = b["s1"].cpu().numpy()        # after the swap: the stacks the LAST step observed
+    ref = onet.forward(host, states, arch, dtype=np.float64)
+    assert np.abs(a["probs"].cpu().numpy() - ref["pi"]).max() < 1e-5
+    assert np.abs(a["val"].cpu().numpy() - ref["v"]).max() < 1e-4
+    ctx.close()
