@@ -103,14 +103,15 @@ int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states
  * then ONE launch that finishes the heads (bias, softmax; probabilities and values also written to probs_out [N,A] /
  * values_out [N]), samples the actions exactly like paac_sample_mt (np.random.multinomial(1, p - epsneg) per
  * environment on the MT19937 state, advanced in place) and steps the synthetic environments like paac_synth_step
- * (stack_out = shifted stacks with the new frame; rewards / masks / episode bookkeeping).
+ * (stack_out = shifted stacks with the new frame, stack_out2 (nullable) = a second copy of them; rewards / masks /
+ * episode bookkeeping).
  * Requires N <= PAAC_ACT_STEP_MAX_ENVS and N*(A-1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS. */
 #define PAAC_ACT_STEP_MAX_ENVS 64
 int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
                      uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
-                     float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
-                     paac_stream_t stream);
+                     uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
+                     void* finished, paac_stream_t stream);
 
 /* Conv-weight packing.  The Nature conv layers run as one fused launch that reads the conv weights pre-split into bf16
  * planes (an internal copy owned by the ctx).  By default every paac_forward* / paac_train_forward / paac_loss_backward
@@ -213,12 +214,13 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
                     void* finished, uint8_t* raw_scratch, paac_stream_t stream);
 
 /* paac_sample_mt + paac_synth_step (path A) in ONE launch: workgroup 0 samples (numpy-parity MT19937 stream) and does
- * the per-env bookkeeping while the other workgroups shift the observation stacks.  Limit: N*(A-1) <= 1024. */
+ * the per-env bookkeeping while the other workgroups shift the observation stacks (stack_out2, nullable: a second copy
+ * of the new stacks, like paac_synth_step's).  Limit: N*(A-1) <= 1024. */
 #define PAAC_FUSED_SAMPLE_MAX_DRAWS 1024
 int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
-                              uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, float* rewards_out,
-                              float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
+                              uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
+                              float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
                               paac_stream_t stream);
 
 /* hipGraph helpers: capture every launch issued on `stream` between begin/end, replay with launch. */

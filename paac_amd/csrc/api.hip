@@ -276,8 +276,8 @@ int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uin
 int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
                      uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
-                     float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
-                     paac_stream_t stream) {
+                     uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
+                     void* finished, paac_stream_t stream) {
   PAAC_REQUIRE(ctx && params && states && mt_state && actions && probs_out && values_out && stack_out && rewards_out &&
                masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS,
@@ -285,14 +285,15 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
   PAAC_REQUIRE((int64_t)batch * (ctx->cfg.num_actions - 1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS,
                "paac_act_step_mt: N*(A-1) = %ld exceeds %d (use paac_forward + paac_sample_mt + paac_synth_step)",
                (long)batch * (ctx->cfg.num_actions - 1), PAAC_FUSED_SAMPLE_MAX_DRAWS);
-  PAAC_REQUIRE(states != stack_out, "paac_act_step_mt: the step cannot shift the stacks in place");
+  PAAC_REQUIRE(states != stack_out && states != stack_out2, "paac_act_step_mt: the step cannot shift the stacks in place");
   const float *partial, *ba, *bc;
   int ntiles;
   int rc = launch_forward_trunk(ctx, params, states, batch, &partial, &ntiles, &ba, &bc, (hipStream_t)stream);
   if (rc) return rc;
   rc = launch_sample_env_step_heads(partial, ntiles, ba, bc, probs_out, values_out, ctx->cfg.num_actions, mt_state, actions,
                                     env_seed, env_offset, batch, terminal_threshold, step_base_dev, step_offset, states,
-                                    stack_out, rewards_out, masks_out, ep_reward, ep_len, finished, (hipStream_t)stream);
+                                    stack_out, stack_out2, rewards_out, masks_out, ep_reward, ep_len, finished,
+                                    (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;

@@ -172,8 +172,8 @@ int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* stat
 int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,
                                  float* values_out, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                                  uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
-                                 const uint8_t* stack_in, uint8_t* stack_out, float* rewards, float* masks,
-                                 float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s);
+                                 const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
+                                 float* masks, float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s);
 

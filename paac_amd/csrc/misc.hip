@@ -545,7 +545,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
                                                               uint32_t env_offset, int N, uint32_t thresh,
                                                               const uint64_t* __restrict__ step_base, uint64_t step_off,
                                                               const uint32_t* __restrict__ stack_in,
-                                                              uint32_t* __restrict__ stack_out, float* rewards_out,
+                                                              uint32_t* __restrict__ stack_out,
+                                                              uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                               float* masks_out, float* ep_reward, int32_t* ep_len,
                                                               FinishedRing* fin) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     MISC_STAMP(8);
     return;
   }
-  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out);
+  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
 }
 
 // The same launch with the heads finish in front of the sampler: workgroup 0 sums the fc kernel's per-tile head partials
@@ -582,7 +583,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
                                                                uint32_t env_offset, int N, uint32_t thresh,
                                                                const uint64_t* __restrict__ step_base, uint64_t step_off,
                                                                const uint32_t* __restrict__ stack_in,
-                                                               uint32_t* __restrict__ stack_out, float* rewards_out,
+                                                               uint32_t* __restrict__ stack_out,
+                                                               uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                                float* masks_out, float* ep_reward, int32_t* ep_len,
                                                                FinishedRing* fin) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
     }
     return;
   }
-  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out);
+  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
 }
 
 // Path B, stage 1: generate the two raw 210x160 gray frames of this step + bookkeeping.
@@ -734,22 +736,102 @@ __global__ __launch_bounds__(NORM_BLOCKS) void grad_stats_kernel(const float* __
 
 constexpr int RMS_U = 4;   // float4 per thread and array in rmsprop_kernel
 
+// What the optimizer step also maintains (csrc/tower.h, csrc/fc_heads.h): the pre-split bf16 planes of the Nature conv
+// weights and the fragment-ordered copy of the fc weights -- written by the workgroup that has just updated the values, so
+// no separate pack launch (and no second pass over 6.7 MB) follows an update.
+struct PackSpec {
+  // conv tensors [K, cout] at float offset conv_begin: tile blocks of 32 rows (one k-step) x cout columns
+  int nconv;
+  long conv_begin[3];
+  int conv_cout[3], conv_tiles[3];   // tiles = K / 32
+  long conv_dst[3];                  // offset of the layer inside the pack buffer, in 16-byte vectors
+  bf16x8* conv_pack;                 // nullptr: no conv pack (NIPS, PAAC_TOWER=0)
+  // fc weights [K, H] at float offset fc_begin: tile blocks of 16 rows x 256 columns
+  long fc_begin;
+  int fc_K, fc_H;
+  float* fc_pack;                    // nullptr: no fc pack
+  // everything the tile blocks do not own, as float4 ranges walked by the flat blocks
+  int nflat;
+  long flat_begin4[5], flat_count4[5];
+};
+
+// One optimizer element update (TF ApplyRMSProp, actor_learner.py:31-34).
+template <bool MOM>
+__device__ __forceinline__ void rms_update4(float4& gv, float4& m, float4& mo, float4& v, const float f, const float lr,
+                                            const float omd, const float momentum, const float eps) {
+#define PAAC_RMS(c)                                        \
+  {                                                        \
+    const float gg = gv.c * f;                             \
+    m.c = m.c + (gg * gg - m.c) * omd;                     \
+    const float step = lr * gg / sqrtf(m.c + eps);         \
+    mo.c = MOM ? momentum * mo.c + step : step;            \
+    v.c = v.c - mo.c;                                      \
+  }
+  PAAC_RMS(x) PAAC_RMS(y) PAAC_RMS(z) PAAC_RMS(w)
+#undef PAAC_RMS
+}
+
 // MOM = false: momentum == 0 (the reference's setting, actor_learner.py:31-34): the momentum slot is written (it
 // is checkpointed as OptimizerVariables_1) but not read.
+// Block classes by blockIdx: [0, fc_tiles) one 16 x 256 tile of the fc weights; then one 32 x cout tile of a conv weight
+// tensor each; then flat blocks over everything else.  A tile block streams its rows coalesced like a flat block, then
+// passes the updated values through LDS into the packed order (fragments of fc_heads.h / bf16 planes of tower.h).
 template <bool MOM>
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, const float* __restrict__ g,
                                                       float* __restrict__ ms, float* __restrict__ mom, long n4,
                                                       const float* __restrict__ lr_dev, float decay, float momentum,
                                                       float eps, float clip_norm, int clip_mode, float scale,
-                                                      const float* __restrict__ partials, float* __restrict__ gnorm_out) {
+                                                      const float* __restrict__ partials, float* __restrict__ gnorm_out,
+                                                      const PackSpec pk, const int fc_tiles, const int conv_tiles) {
+  __shared__ float red[4];
+  __shared__ float s_factor;
+  __shared__ float tile[32 * 68 > 16 * 260 ? 32 * 68 : 16 * 260];
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  const int cls = bid < fc_tiles ? 0 : (bid < fc_tiles + conv_tiles ? 1 : 2);
+  // ---- which float4s does this thread own ----------------------------------------------------------------------------
+  long idx[RMS_U];       // float4 index of each of this thread's elements, -1 = none
+  int cl = 0, ct_i = 0, ccout = 64;          // conv tile: layer, tile (k-step), columns
+  if (cls == 0) {
+    const int cblocks = pk.fc_H / 256;
+    const int gI = bid / cblocks, cb = bid - gI * cblocks;
+#pragma unroll
+    for (int u = 0; u < RMS_U; ++u) {
+      const int f = tid + 256 * u;           // float4 inside the tile: row f / 64, column group f % 64
+      idx[u] = (pk.fc_begin + (long)(16 * gI + (f >> 6)) * pk.fc_H + 256 * cb + 4 * (f & 63)) >> 2;
+    }
+  } else if (cls == 1) {
+    int t = bid - fc_tiles;
+    while (cl < pk.nconv - 1 && t >= pk.conv_tiles[cl]) t -= pk.conv_tiles[cl++];
+    ct_i = t;
+    ccout = pk.conv_cout[cl];
+    const int f4_per_tile = 32 * ccout / 4;  // 512 (cout 64) or 256 (cout 32): rows are contiguous, so is the tile
+#pragma unroll
+    for (int u = 0; u < RMS_U; ++u) {
+      const int f = tid + 256 * u;
+      idx[u] = f < f4_per_tile ? ((pk.conv_begin[cl] + (long)ct_i * 32 * ccout) >> 2) + f : -1;
+    }
+  } else {
+    const long i0 = (long)(bid - fc_tiles - conv_tiles) * (256 * RMS_U) + tid;
+#pragma unroll
+    for (int u = 0; u < RMS_U; ++u) {
+      long i = i0 + u * 256;
+      long at = -1;
+#pragma unroll
+      for (int sgm = 0; sgm < 5; ++sgm) {
+        if (sgm < pk.nflat && at < 0) {
+          if (i < pk.flat_count4[sgm]) at = pk.flat_begin4[sgm] + i;
+          else i -= pk.flat_count4[sgm];
+        }
+      }
+      idx[u] = at;
+    }
+  }
   // the streams do not depend on the norm: request them first (RMS_U float4 per thread and array), reduce the
   // partials while they are in flight
-  const long i0 = (long)blockIdx.x * (256 * RMS_U) + threadIdx.x;
   float4 gv[RMS_U], m[RMS_U], mo[RMS_U], v[RMS_U];
 #pragma unroll
   for (int u = 0; u < RMS_U; ++u) {
-    const long i = i0 + u * 256;
-    const long il = i < n4 ? i : 0;
+    const long il = idx[u] >= 0 ? idx[u] : 0;
     gv[u] = reinterpret_cast<const float4*>(g)[il];
     m[u] = reinterpret_cast<float4*>(ms)[il];
     mo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -758,53 +840,136 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
   }
   const float lr = *lr_dev;
   // every block reduces the same 256 partials in the same order -> identical norm everywhere
-  float acc = partials[threadIdx.x];
+  float acc = partials[tid];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  __shared__ float red[4];
-  __shared__ float s_factor;
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     const float gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
     float f = 1.f;
     if (clip_mode == PAAC_CLIP_GLOBAL) f = clip_norm * fminf(1.0f / gn, 1.0f / clip_norm);
     s_factor = f;
-    if (gnorm_out && blockIdx.x == 0) *gnorm_out = gn;
+    if (gnorm_out && bid == 0) *gnorm_out = gn;
   }
   __syncthreads();
   const float f = s_factor * scale;
   const float omd = 1.0f - decay;
-#define PAAC_RMS(c)                                              \
-  {                                                              \
-    const float gg = gv[u].c * f;                                \
-    m[u].c = m[u].c + (gg * gg - m[u].c) * omd;                  \
-    const float step = lr * gg / sqrtf(m[u].c + eps);            \
-    mo[u].c = MOM ? momentum * mo[u].c + step : step;            \
-    v[u].c = v[u].c - mo[u].c;                                   \
-  }
 #pragma unroll
   for (int u = 0; u < RMS_U; ++u) {
-    const long i = i0 + u * 256;
-    if (i < n4) {
-      PAAC_RMS(x) PAAC_RMS(y) PAAC_RMS(z) PAAC_RMS(w)
-      reinterpret_cast<float4*>(ms)[i] = m[u];
-      reinterpret_cast<float4*>(mom)[i] = mo[u];
-      reinterpret_cast<float4*>(var)[i] = v[u];
+    if (idx[u] < 0) continue;
+    rms_update4<MOM>(gv[u], m[u], mo[u], v[u], f, lr, omd, momentum, eps);
+    reinterpret_cast<float4*>(ms)[idx[u]] = m[u];
+    reinterpret_cast<float4*>(mom)[idx[u]] = mo[u];
+    reinterpret_cast<float4*>(var)[idx[u]] = v[u];
+  }
+  if (cls == 0) {
+    // fc tile -> fragments [tile nt][group g][lane = 16 kq + li][s] = W[16 g + 4 kq + s][16 nt + li]
+    float (*tl)[260] = reinterpret_cast<float (*)[260]>(tile);
+#pragma unroll
+    for (int u = 0; u < RMS_U; ++u) {
+      const int fidx = tid + 256 * u;
+      *reinterpret_cast<float4*>(&tl[fidx >> 6][4 * (fidx & 63)]) = v[u];
+    }
+    __syncthreads();
+    const int cblocks = pk.fc_H / 256, G = pk.fc_K / 16;
+    const int gI = bid / cblocks, cb = bid - gI * cblocks;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + 256 * j;           // fragment: local tile q / 64, lane q % 64
+      const int ntl = q >> 6, lane = q & 63, li = lane & 15, kq = lane >> 4;
+      float4 o;
+      o.x = tl[4 * kq + 0][16 * ntl + li];
+      o.y = tl[4 * kq + 1][16 * ntl + li];
+      o.z = tl[4 * kq + 2][16 * ntl + li];
+      o.w = tl[4 * kq + 3][16 * ntl + li];
+      reinterpret_cast<float4*>(pk.fc_pack)[((long)(16 * cb + ntl) * G + gI) * 64 + lane] = o;
+    }
+  } else if (cls == 1) {
+    // conv tile (k-step ct_i: 32 rows x cout) -> per 16-channel tile three planes of 64 lanes x 8 bf16 (tower.h):
+    // lane (ch = l & 15, kq = l >> 4) holds W[32 s + 8 kq + j][16 ct + ch], j = 0..7
+    float (*tl)[68] = reinterpret_cast<float (*)[68]>(tile);
+    const int f4_per_row = ccout / 4;
+#pragma unroll
+    for (int u = 0; u < RMS_U; ++u) {
+      if (idx[u] < 0) continue;
+      const int fidx = tid + 256 * u;
+      *reinterpret_cast<float4*>(&tl[fidx / f4_per_row][4 * (fidx % f4_per_row)]) = v[u];
+    }
+    __syncthreads();
+    const int ctiles = ccout / 16;
+    for (int q = tid; q < ctiles * 64; q += 256) {
+      const int ct = q >> 6, lane = q & 63, ch = lane & 15, kq = lane >> 4;
+      float x[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) x[jj] = tl[8 * kq + jj][16 * ct + ch];
+      bf16x8 h, md, l;
+      split3_bf16(x, h, md, l);
+      bf16x8* dst = pk.conv_pack + pk.conv_dst[cl] + ((long)ct_i * ctiles + ct) * 192 + lane;
+      dst[0] = h;
+      dst[64] = md;
+      dst[128] = l;
     }
   }
-#undef PAAC_RMS
+}
+
+// The packed copies the optimizer step maintains and the block classes that go with them (from the ctx's layout).
+static void fill_pack_spec(const paac_ctx* ctx, PackSpec* pk, int* fc_tiles, int* conv_tiles, long* flat4) {
+  const paac_layout& L = ctx->layout;
+  const ArchSpec& sp = ctx->spec;
+  memset(pk, 0, sizeof(*pk));
+  *fc_tiles = 0;
+  *conv_tiles = 0;
+  long owned_begin[4], owned_end[4];   // float ranges the tile blocks own, ascending
+  int nowned = 0;
+  if (ctx->tower_on && ctx->tower_pack) {
+    pk->nconv = sp.nconv;
+    long dst = 0;
+    for (int i = 0; i < sp.nconv; ++i) {
+      const long K = (long)sp.conv[i].k * sp.conv[i].k * sp.conv[i].cin;
+      pk->conv_begin[i] = L.offset[2 * i];
+      pk->conv_cout[i] = sp.conv[i].cout;
+      pk->conv_tiles[i] = (int)(K / 32);
+      pk->conv_dst[i] = dst;
+      dst += (K / 32) * (sp.conv[i].cout / 16) * 192;
+      *conv_tiles += pk->conv_tiles[i];
+      owned_begin[nowned] = L.offset[2 * i];
+      owned_end[nowned++] = L.offset[2 * i] + K * sp.conv[i].cout;
+    }
+    pk->conv_pack = reinterpret_cast<bf16x8*>(ctx->tower_pack);
+  }
+  if (ctx->fc_pack && sp.fc % 256 == 0) {
+    pk->fc_begin = L.offset[2 * sp.nconv];
+    pk->fc_K = sp.flat;
+    pk->fc_H = sp.fc;
+    pk->fc_pack = reinterpret_cast<float*>(ctx->fc_pack);
+    *fc_tiles = (sp.flat / 16) * (sp.fc / 256);
+    owned_begin[nowned] = pk->fc_begin;
+    owned_end[nowned++] = pk->fc_begin + (long)sp.flat * sp.fc;
+  }
+  long at = 0;
+  *flat4 = 0;
+  for (int i = 0; i <= nowned; ++i) {
+    const long end = i < nowned ? owned_begin[i] : L.total;
+    if (end > at) {
+      pk->flat_begin4[pk->nflat] = at / 4;
+      pk->flat_count4[pk->nflat] = (end - at) / 4;
+      *flat4 += (end - at) / 4;
+      ++pk->nflat;
+    }
+    if (i < nowned) at = owned_end[i];
+  }
 }
 
 int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,
                                  float* values_out, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                                  uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
-                                 const uint8_t* stack_in, uint8_t* stack_out, float* rewards, float* masks,
-                                 float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s) {
+                                 const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
+                                 float* masks, float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s) {
   ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, s);
   launch_k(synth_step_a_mth_kernel, dim3(1 + N * PRE_BANDS), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
            values_out, A, mt_state, actions, seed, env_offset, N, thresh, step_base, step_off, (const uint32_t*)stack_in,
-           (uint32_t*)stack_out, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished);
+           (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished);
   return 0;
 }
 
@@ -975,8 +1140,8 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
 
 int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
-                              uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, float* rewards_out,
-                              float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
+                              uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
+                              float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
                               paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
   PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
@@ -986,7 +1151,7 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
   ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, (hipStream_t)stream);
   launch_k(synth_step_a_mt_kernel, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
            actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
-           (uint32_t*)stack_out, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
+           (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1002,16 +1167,17 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   ProfScope ps(ctx, F_CLIP_RMSPROP, (int)(n / 4), s);
   const long n4 = n / 4;
   launch_k(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), s, PROF_FIRST, grad, n4, grad_scale, ctx->partials);
+  PackSpec pk;
+  int fc_tiles, conv_tiles;
+  long flat4;
+  fill_pack_spec(ctx, &pk, &fc_tiles, &conv_tiles, &flat4);
+  const dim3 grid((unsigned)(fc_tiles + conv_tiles + (flat4 + 256 * RMS_U - 1) / (256 * RMS_U)));
   if (momentum != 0.f)
-    launch_k(rmsprop_kernel<true>, dim3((n4 + 256 * RMS_U - 1) / (256 * RMS_U)), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
-             decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
+    launch_k(rmsprop_kernel<true>, grid, dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev, decay, momentum, eps,
+             clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out, pk, fc_tiles, conv_tiles);
   else
-    launch_k(rmsprop_kernel<false>, dim3((n4 + 256 * RMS_U - 1) / (256 * RMS_U)), dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev,
-             decay, momentum, eps, clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out);
-  {   // the conv tower's pre-split copy of the conv weights follows every optimizer step
-    const int rc = launch_pack_weights(ctx, params, s);
-    if (rc) return rc;
-  }
+    launch_k(rmsprop_kernel<false>, grid, dim3(256), s, PROF_LAST, params, grad, ms, mom, n4, lr_dev, decay, momentum, eps,
+             clip_norm, clip_mode, grad_scale, (const float*)ctx->partials, gnorm_out, pk, fc_tiles, conv_tiles);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

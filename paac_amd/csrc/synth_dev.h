@@ -62,7 +62,8 @@ __device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_
 // Frame shift of one (env, band) unit of path A: push the step's new 84x84 plane into the 4-deep history
 // (one dword = the 4 channels of a pixel).  unit = env * PRE_BANDS + band; 256 threads.
 __device__ __forceinline__ void synth_shift_band(uint64_t seed, uint32_t env_offset, uint64_t id, uint32_t thresh, int unit,
-                                                 const uint32_t* __restrict__ stack_in, uint32_t* __restrict__ stack_out) {
+                                                 const uint32_t* __restrict__ stack_in, uint32_t* __restrict__ stack_out,
+                                                 uint32_t* __restrict__ stack_out2 = nullptr) {
   const int e = unit / PRE_BANDS;
   const int band = unit % PRE_BANDS;
   const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
@@ -75,7 +76,9 @@ __device__ __forceinline__ void synth_shift_band(uint64_t seed, uint32_t env_off
     const uint32_t nv = (w >> (8 * (x & 3))) & 255u;
     const long pix = (long)e * OBS_PIX + p;
     const uint32_t old = reset ? 0u : stack_in[pix];
-    stack_out[pix] = (old >> 8) | (nv << 24);
+    const uint32_t outv = (old >> 8) | (nv << 24);
+    stack_out[pix] = outv;
+    if (stack_out2) stack_out2[pix] = outv;      // second copy of the new stacks (the observation ring's wrap-around slot)
   }
 }
 

@@ -164,7 +164,7 @@ class Context(object):
 
     def act_step_mt(self, params, states, mt_state, actions, probs_out, values_out, env_seed, env_offset,
                     terminal_threshold, step_base_dev, step_offset, stack_out, rewards_out, masks_out, ep_reward, ep_len,
-                    finished=None):
+                    finished=None, stack_out2=None):
         """One acting step in three launches: policy forward, then heads finish + numpy-parity sampler + synthetic
         environment step in one (include/paac_hip.h: paac_act_step_mt)."""
         N, A = self._check_states(states), self.num_actions
@@ -172,7 +172,7 @@ class Context(object):
             raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS, FUSED_SAMPLE_MAX_DRAWS))
         if tuple(stack_out.shape) != (N,) + OBS_SHAPE:
             raise ValueError("stack_out must be [%d,84,84,4], got %s" % (N, tuple(stack_out.shape)))
-        if states.data_ptr() == stack_out.data_ptr():
+        if states.data_ptr() == stack_out.data_ptr() or (stack_out2 is not None and states.data_ptr() == stack_out2.data_ptr()):
             raise ValueError("the step cannot shift the stacks in place")
         if finished is not None and finished.numel() * finished.element_size() < FINISHED_RING_BYTES:
             raise ValueError("finished ring too small")
@@ -182,7 +182,8 @@ class Context(object):
             _ptr(actions, torch.int32, N, "actions"), _ptr(probs_out, torch.float32, N * A, "probs_out"),
             _ptr(values_out, torch.float32, N, "values_out"), int(env_seed), int(env_offset), int(terminal_threshold),
             _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
-            _ptr(stack_out, torch.uint8, N * 28224, "stack_out"), _ptr(rewards_out, torch.float32, N, "rewards_out"),
+            _ptr(stack_out, torch.uint8, N * 28224, "stack_out"), _ptr(stack_out2, torch.uint8, N * 28224, "stack_out2", True),
+            _ptr(rewards_out, torch.float32, N, "rewards_out"),
             _ptr(masks_out, torch.float32, N, "masks_out"), _ptr(ep_reward, torch.float32, N, "ep_reward"),
             _ptr(ep_len, torch.int32, N, "ep_len"),
             ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),
@@ -369,7 +370,7 @@ ACT_STEP_MAX_ENVS = 64
 
 
 def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_threshold, step_base_dev, step_offset,
-                         stack_in, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None):
+                         stack_in, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None, stack_out2=None):
     N, A = probs.shape
     if N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
         raise ValueError("fused sampler+env step supports N*(A-1) <= %d" % FUSED_SAMPLE_MAX_DRAWS)
@@ -383,6 +384,7 @@ def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_th
         _ptr(actions, torch.int32, N, "actions"), int(seed), int(env_offset), N, int(terminal_threshold),
         _ptr(step_base_dev, torch.int64, 1, "step_base", True), int(step_offset),
         _ptr(stack_in, torch.uint8, N * 28224, "stack_in"), _ptr(stack_out, torch.uint8, N * 28224, "stack_out"),
+        _ptr(stack_out2, torch.uint8, N * 28224, "stack_out2", True),
         _ptr(rewards_out, torch.float32, N, "rewards_out"), _ptr(masks_out, torch.float32, N, "masks_out"),
         _ptr(ep_reward, torch.float32, N, "ep_reward"), _ptr(ep_len, torch.int32, N, "ep_len"),
         ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),

@@ -41,8 +41,8 @@ class DeviceRollout(object):
         self.use_graph = use_graph
         # Observation buffer of 2T+1 slots: even cycles use slots 0..T, odd cycles T..2T, so the last observation of
         # an even cycle IS the first of the odd one, and the T+1 observations of a cycle are contiguous (one
-        # forward at batch N*(T+1) serves the update and the bootstrap); an odd cycle ends by copying slot 2T to
-        # slot 0.  Two captured graphs alternate.
+        # forward at batch N*(T+1) serves the update and the bootstrap); the last environment step of an odd cycle
+        # writes its new stacks to slot 2T AND to slot 0 (stack_out2).  Two captured graphs alternate.
         self.states = torch.zeros((2 * T + 1, N, 84, 84, 4), dtype=torch.uint8, device=dev)
         self.values_train = torch.zeros(((T + 1) * N,), dtype=torch.float32, device=dev)
         self.parity = 0
@@ -98,12 +98,15 @@ class DeviceRollout(object):
         params = L.network.params
         st = [self.states[self._slot(parity, t)] for t in range(T + 1)]
         for t in range(T):
+            # the ring wraps after an odd cycle: its last step also writes slot 0 (the next even cycle's first slot)
+            wrap = self.states[0] if (parity == 1 and t == T - 1) else None
             fused = self.sampler == "numpy" and self.raw is None and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS
             if fused and N <= hip_ops.ACT_STEP_MAX_ENVS:
                 # the whole step in three launches: conv tower, fc + head partials, heads finish + sampler + env step
                 L.ctx.act_step_mt(params, st[t], self.mt_state, self.actions[t], self.probs, self.values[t],
                                   self.env_spec["seed"], self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
-                                  st[t + 1], self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished)
+                                  st[t + 1], self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
+                                  stack_out2=wrap)
                 continue
             if fused:
                 # numpy-parity sampler and env step in one launch (the frame shift does not need the action)
@@ -111,7 +114,7 @@ class DeviceRollout(object):
                 hip_ops.sample_mt_synth_step(self.probs, self.mt_state, self.actions[t], self.env_spec["seed"],
                                              self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
                                              st[t], st[t + 1], self.rewards[t], self.masks[t], self.ep_reward,
-                                             self.ep_len, self.finished)
+                                             self.ep_len, self.finished, stack_out2=wrap)
                 continue
             if self.sampler == "numpy":
                 L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
@@ -122,6 +125,8 @@ class DeviceRollout(object):
                                                 self.env_spec["terminal_threshold"], st[t + 1], self.rewards[t],
                                                 self.masks[t], self.ep_reward, self.ep_len, self.finished,
                                                 probs=self.probs, values=self.values[t])
+                if wrap is not None:          # this launch has no second output
+                    wrap.copy_(st[t + 1])
                 continue
             else:       # counter-based sampler fused into the heads kernel
                 L.ctx.forward_sample(params, st[t], self.sampler_seed, self.tick, t, self.env_offset,
@@ -129,9 +134,7 @@ class DeviceRollout(object):
             hip_ops.synth_step(self.env_spec["seed"], self.env_offset, self.actions[t],
                                self.env_spec["terminal_threshold"], self.tick, t, st[t], st[t + 1],
                                self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
-                               raw_scratch=self.raw)
-        if parity == 1:
-            self.states[0].copy_(self.states[2 * T])
+                               stack_out2=wrap, raw_scratch=self.raw)
         # training forward over the T*N rollout rows with the N bootstrap observations appended (paac.py:140-142)
         L.ctx.train_forward(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4),
                             values=self.values_train)

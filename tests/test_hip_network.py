@@ -390,3 +390,36 @@ def test_conv_tower_variants(regions, B, A):
     ctx.forward(p2, s, logits=logits3)
     assert not torch.equal(logits2, logits3)
     ctx.close()
+
+
+@pytest.mark.parametrize("arch,A", [("NATURE", 4), ("NIPS", 6)])
+def test_optimizer_step_keeps_packed_weights_current(arch, A):
+    """paac_clip_rmsprop also rewrites the pre-split conv planes (tower.h) and the fragment-ordered fc weights (fc_heads.h)
+    from the values it has just computed: a managed-mode forward right after an update equals the forward after an explicit
+    paac_pack_weights of the same parameters, bit for bit -- and differs from the forward before the update."""
+    from paac_amd import hip_ops, _lib
+    B = 24
+    params, states, idx, y, adv = make_case(arch, A, B, seed=9)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    ctx.set_managed_weights(True)
+    ctx.pack_weights(p)
+    n = ctx.layout["total"]
+    before = torch.zeros((B, A), device="cuda")
+    ctx.forward(p, s, logits=before)
+    grad = torch.zeros(n, device="cuda")
+    ctx.loss_backward(p, s, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(adv).cuda(), 0.02, grad)
+    ctx.clip_rmsprop(p, grad, torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.tensor([0.05], device="cuda"),
+                     0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL)
+    after = torch.zeros((B, A), device="cuda")
+    ctx.forward(p, s, logits=after)              # packed copies as left by the optimizer step
+    ctx.pack_weights(p)
+    repacked = torch.zeros((B, A), device="cuda")
+    ctx.forward(p, s, logits=repacked)
+    torch.cuda.synchronize()
+    assert torch.equal(after, repacked)
+    assert not torch.equal(after, before)
+    ref = onet.forward(unflatten(ctx, p), states, arch, dtype=np.float64)
+    assert np.abs(after.cpu().numpy() - ref["logits"]).max() < 1e-4
+    ctx.close()
