@@ -167,6 +167,7 @@ int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t
                                uint8_t* stack_out, float* rewards, float* masks, float* ep_reward, int32_t* ep_len,
                                void* finished, hipStream_t s);
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s);
+int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s);
 int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, const float** partial,
                          int* ntiles, const float** ba, const float** bc, hipStream_t s);
 int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,

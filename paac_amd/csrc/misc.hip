@@ -3,6 +3,7 @@
 #include "common.h"
 #include "synth_dev.h"
 #include "fc_heads.h"
+#include "tower.h"
 
 namespace paac {
 
@@ -746,6 +747,8 @@ struct PackSpec {
   int conv_cout[3], conv_tiles[3];   // tiles = K / 32
   long conv_dst[3];                  // offset of the layer inside the pack buffer, in 16-byte vectors
   bf16x8* conv_pack;                 // nullptr: no conv pack (NIPS, PAAC_TOWER=0)
+  bf16x8* dgrad3_pack;               // conv3 / conv2 data-gradient planes (dgrad_tower.h), with conv_pack
+  bf16x8* dgrad2_pack;
   // fc weights [K, H] at float offset fc_begin: tile blocks of 16 rows x 256 columns
   long fc_begin;
   int fc_K, fc_H;
@@ -910,6 +913,31 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
       dst[64] = md;
       dst[128] = l;
     }
+    // the same tile in the data-gradient order (dgrad_tower.h): row r = input channel, 8 consecutive columns = 8
+    // consecutive output channels = one vector of the transposed, tap-flipped weight matrix; 32 rows x 8 groups = one
+    // vector per thread
+    if (cl >= 1 && ccout == 64) {
+      const int r = tid >> 3, q8 = tid & 7;
+      float x[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) x[jj] = tl[r][8 * q8 + jj];
+      bf16x8 h, md, l;
+      split3_bf16(x, h, md, l);
+      bf16x8* dst;
+      if (cl == 2) {                       // conv3: tile = (tap kh*3+kw, input-channel half)
+        const int tap_d = 8 - (ct_i >> 1), c2 = 32 * (ct_i & 1) + r;
+        const int sI = 2 * tap_d + (q8 >> 2);
+        dst = pk.dgrad3_pack + ((long)sI * 4 + (c2 >> 4)) * 192 + (q8 & 3) * 16 + (c2 & 15);
+      } else {                             // conv2: tile = tap kh*4+kw, rows = its 32 input channels
+        const int kh = ct_i >> 2, kw = ct_i & 3;
+        const int clsI = (kh & 1) * 2 + (kw & 1), tap_d = (1 - (kh >> 1)) * 2 + (1 - (kw >> 1));
+        const int sI = 2 * tap_d + (q8 >> 2);
+        dst = pk.dgrad2_pack + ((long)(clsI * 8 + sI) * 2 + (r >> 4)) * 192 + (q8 & 3) * 16 + (r & 15);
+      }
+      dst[0] = h;
+      dst[64] = md;
+      dst[128] = l;
+    }
   }
 }
 
@@ -937,6 +965,8 @@ static void fill_pack_spec(const paac_ctx* ctx, PackSpec* pk, int* fc_tiles, int
       owned_end[nowned++] = L.offset[2 * i] + K * sp.conv[i].cout;
     }
     pk->conv_pack = reinterpret_cast<bf16x8*>(ctx->tower_pack);
+    pk->dgrad3_pack = pk->conv_pack + kTowerPackVecs;
+    pk->dgrad2_pack = pk->dgrad3_pack + kDgradW3Vecs;
   }
   if (ctx->fc_pack && sp.fc % 256 == 0) {
     pk->fc_begin = L.offset[2 * sp.nconv];

@@ -1,5 +1,6 @@
 // Backward half of the actor-critic network (see net_fwd.hip): dgrad / wgrad launches, slab finalize, launch tuning.
 #include "net_common.h"
+#include "dgrad_tower.h"
 
 namespace paac {
 
@@ -165,6 +166,16 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinalizeArgs a
   if (live && r == 0) *reinterpret_cast<f32x4*>(sg.dst + i) = v;
 }
 
+int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s) {
+  if (!ctx->tower_on) return 0;
+  const paac_layout& L = ctx->layout;
+  bf16x8* base = reinterpret_cast<bf16x8*>(ctx->tower_pack) + kTowerPackVecs;
+  constexpr int threads = 18 * 4 * 64 + 4 * 8 * 2 * 64;
+  launch_k(pack_dgrad_kernel, dim3((threads + 255) / 256), dim3(256), s, PROF_NONE, params + L.offset[2], params + L.offset[4],
+           base, base + kDgradW3Vecs);
+  return 0;
+}
+
 // phase: 0 = whole backward; 1 = heads + fc (gradients of fc_w .. critic_b, the contiguous tail of the flat
 // buffer, 95 % of its bytes); 2 = conv layers (the head of the flat buffer) + slab finalize.  The split lets a
 // data-parallel caller all-reduce the tail while phase 2 still computes.
@@ -235,8 +246,24 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
       splits = launch_wgrad<typename NT::G3, false, NT::C3>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], s);
     }
-    ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
-    launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(gd, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
+    if (ctx->tower_on) {
+      // conv3 AND conv2 data gradients in one launch (dgrad_tower.h): da2 -> dact[1], da1 -> dact[0]
+      ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
+      DgradTowerArgs da;
+      da.da3 = ctx->dact[2];
+      da.act2 = W.act[1];
+      da.act1 = W.act[0];
+      const bf16x8* base = reinterpret_cast<const bf16x8*>(ctx->tower_pack) + kTowerPackVecs;
+      da.w3d = base;
+      da.w2d = base + kDgradW3Vecs;
+      da.da2 = ctx->dact[1];
+      da.da1 = ctx->dact[0];
+      da.batch = batch;
+      launch_k(dgrad_tower_kernel, dim3((unsigned)batch), dim3(512), s, PROF_WHOLE, da);
+    } else {
+      ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
+      launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(gd, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
+    }
     wgrad_out(i_w3, feats, NT::C3, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
   }
@@ -256,8 +283,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
       splits = launch_wgrad<typename NT::G2, false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], s);
     }
-    ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
-    launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(gd, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
+    if (!(NT::NCONV == 3 && ctx->tower_on)) {     // Nature with the tower: done by dgrad_tower_kernel above
+      ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
+      launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(gd, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
+    }
     wgrad_out(i_w2, feats, NT::C2, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C2;
   }

@@ -87,7 +87,7 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Conv tower (tower.h): Nature conv1 -> conv2 -> conv3 in one launch.
-size_t tower_pack_bytes() { return (size_t)kTowerPackVecs * sizeof(bf16x8); }
+size_t tower_pack_bytes() { return (size_t)kTowerPackAllVecs * sizeof(bf16x8); }
 
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
   const paac_layout& L = ctx->layout;
@@ -105,7 +105,7 @@ int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
   constexpr int threads = (8 * 2 + 16 * 4 + 18 * 4) * 64;
   launch_k(pack_tower_kernel, dim3((threads + 255) / 256), dim3(256), s, PROF_NONE, params + L.offset[0], params + L.offset[2],
            params + L.offset[4], reinterpret_cast<bf16x8*>(ctx->tower_pack));
-  return 0;
+  return launch_pack_dgrad(ctx, params, s);
 }
 
 template <class G, bool KEEP>

@@ -63,6 +63,9 @@ struct TowerArgs {
 
 constexpr int kTowerW1Vecs = 8 * 2 * 3 * 64, kTowerW2Vecs = 16 * 4 * 3 * 64, kTowerW3Vecs = 18 * 4 * 3 * 64;   // bf16x8 each
 constexpr int kTowerPackVecs = kTowerW1Vecs + kTowerW2Vecs + kTowerW3Vecs;
+// data-gradient weights of the backward tower (dgrad_tower.h), stored behind the forward planes in the same buffer
+constexpr int kDgradW3Vecs = 18 * 4 * 3 * 64, kDgradW2Vecs = 4 * 8 * 2 * 3 * 64;
+constexpr int kTowerPackAllVecs = kTowerPackVecs + kDgradW3Vecs + kDgradW2Vecs;
 
 // ---------------------------------------------------------------------------------------------
 // Weight packing: fp32 HWIO conv weights ([K, Cout] row-major, K = (kh, kw, cin)) -> per (k-step of 32, 16-channel tile):
@@ -75,7 +78,7 @@ __device__ __forceinline__ void split3_store(const float (&x)[8], bf16x8* dst /*
   dst[128] = l;
 }
 
-__global__ __launch_bounds__(256) void pack_tower_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+static __global__ __launch_bounds__(256) void pack_tower_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
                                                          const float* __restrict__ w3, bf16x8* __restrict__ out) {
   int i = blockIdx.x * 256 + threadIdx.x;   // one thread per (k-step, channel tile, lane)
   const float* w;
@@ -149,7 +152,7 @@ struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <int NS, int NT, int CT, int BP, int BPL, int PF_, class KOFF>
+template <int NS, int NT, int CT, int BP, int BPL, int PF_, class KOFF, bool DB = true>
 struct WaveGemm {
   static constexpr int PF = PF_ < NS ? PF_ : NS;
   static constexpr int RING = PF < NS ? PF + 1 : NS;
@@ -187,28 +190,36 @@ struct WaveGemm {
   template <class Hook = NoHook>
   __device__ __forceinline__ void run(const char* __restrict__ lds_b, const unsigned (&bb)[NT], f32x4 (&acc)[NT],
                                       Hook hook = Hook()) {
-    bf16x8 b[2][NT][BP];
-    read_b(b[0], lds_b, bb, 0);
+    // DB: the patch fragments of step i + 1 are read while step i computes (two register sets); !DB (many tiles per
+    // wave): one set, read at the top of the step
+    bf16x8 b[DB ? 2 : 1][NT][BP];
+    if constexpr (DB) read_b(b[0], lds_b, bb, 0);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       if (i + PF < NS) load_a((i + PF) % RING, i + PF);
       hook(i);
-      if (i + 1 < NS) read_b(b[(i + 1) & 1], lds_b, bb, i + 1);
+      if constexpr (DB) {
+        if (i + 1 < NS) read_b(b[(i + 1) & 1], lds_b, bb, i + 1);
+      } else {
+        read_b(b[0], lds_b, bb, i);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const int slot = i % RING;
+      constexpr int NB = DB ? 2 : 1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+        const bf16x8(&bt)[BP] = b[i % NB][t];
         if constexpr (BP == 1) {
-          acc[t] = mfma_bf16(a[slot][2], b[i & 1][t][0], acc[t]);   // smallest terms first
-          acc[t] = mfma_bf16(a[slot][1], b[i & 1][t][0], acc[t]);
-          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][2], bt[0], acc[t]);   // smallest terms first
+          acc[t] = mfma_bf16(a[slot][1], bt[0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], bt[0], acc[t]);
         } else {
-          acc[t] = mfma_bf16(a[slot][2], b[i & 1][t][0], acc[t]);
-          acc[t] = mfma_bf16(a[slot][1], b[i & 1][t][1], acc[t]);
-          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][2], acc[t]);
-          acc[t] = mfma_bf16(a[slot][1], b[i & 1][t][0], acc[t]);
-          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][1], acc[t]);
-          acc[t] = mfma_bf16(a[slot][0], b[i & 1][t][0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][2], bt[0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][1], bt[1], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], bt[2], acc[t]);
+          acc[t] = mfma_bf16(a[slot][1], bt[0], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], bt[1], acc[t]);
+          acc[t] = mfma_bf16(a[slot][0], bt[0], acc[t]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);

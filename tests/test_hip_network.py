@@ -422,4 +422,15 @@ def test_optimizer_step_keeps_packed_weights_current(arch, A):
     assert not torch.equal(after, before)
     ref = onet.forward(unflatten(ctx, p), states, arch, dtype=np.float64)
     assert np.abs(after.cpu().numpy() - ref["logits"]).max() < 1e-4
+    # the backward pass reads packed data-gradient weights too (dgrad_tower.h): same check on the gradient
+    dev = [torch.from_numpy(a).cuda() for a in (idx, y, adv)]
+    ctx.clip_rmsprop(p, grad, torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.tensor([0.05], device="cuda"),
+                     0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL)
+    g_after = torch.zeros(n, device="cuda")
+    ctx.loss_backward(p, s, *dev, 0.02, g_after)
+    ctx.pack_weights(p)
+    g_repacked = torch.zeros(n, device="cuda")
+    ctx.loss_backward(p, s, *dev, 0.02, g_repacked)
+    torch.cuda.synchronize()
+    assert torch.equal(g_after, g_repacked)
     ctx.close()
