@@ -57,10 +57,12 @@ def family_work(name, batch, arch, A, P, raw=False):
     table = {"conv1_fwd": conv1, "conv1_wgrad": conv1, "conv2_fwd": conv2, "conv2_wgrad": conv2, "conv2_dgrad": conv2,
              "conv3_fwd": conv3, "conv3_wgrad": conv3, "conv3_dgrad": conv3, "fc_fwd": fc, "fc_wgrad": fc, "fc_dgrad": fc}
     table["conv_tower"] = conv1 + conv2 + conv3      # the three conv layers in one launch (csrc/tower.h): algorithmic FLOPs
+    if arch == "NATURE" and os.environ.get("PAAC_TOWER", "1") != "0":
+        table["conv3_dgrad"] = conv3 + conv2         # conv3 AND conv2 data gradients in one launch (csrc/dgrad_tower.h)
     if name in table:
         return "flop", table[name]
     if name == "clip_rmsprop":      # read g (norm) + read g, ms, var + write ms, mom, var (momentum 0: slot not read)
-        return "byte", 4.0 * P * 7
+        return "byte", 4.0 * P * 7  # (+ the packed copies of the conv / fc weights it leaves behind: 4 P more bytes written)
     if name == "heads_fwd":
         return "byte", 4.0 * batch * H * 2 + 4.0 * H * (A + 1)
     if name == "heads_bwd":
@@ -304,11 +306,11 @@ def main():
                                       "synthetic 84x84x4 u8 frames generated on device",
                                       a.sampler, "hipGraph replay" if not a.no_graph else "eager launches"),
                        "envs_per_gpu": N, "t_max": T, "global_envs": N * world,
-                       "arithmetic": "fp32 results everywhere (parity: logits/values within 1e-4). fp32 MFMA for the "
-                                     "32-row kernels; conv1 and most >64-row contractions run on the bf16 MFMA with each "
-                                     "fp32 operand split EXACTLY into 3 bf16 terms (u8 pixels are exact in one), fp32 "
-                                     "accumulation; of the 9 partial products the 3 below 2^-23 of the leading one are "
-                                     "dropped",
+                       "arithmetic": "fp32 results everywhere (parity: logits/values within 1e-4). The Nature conv layers "
+                                     "(forward tower, conv3/conv2 data gradients) and most >64-row contractions run on the "
+                                     "bf16 MFMA with each fp32 operand split EXACTLY into 3 bf16 terms (u8 pixels are exact "
+                                     "in one), fp32 accumulation; of the 9 partial products the 3 below 2^-23 of the leading "
+                                     "one are dropped.  The acting fc layer (<= 64 rows) runs on the fp32 MFMA",
                        "parallelism": "env-sharded dp%d, RCCL sum all-reduce of the flat gradient per update (fc/heads part overlapped with the conv backward)" % world},
             "finite_params": finite,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_plugin_loop": host_loop, "kernels": kernels,

@@ -58,12 +58,12 @@ with open("profiles/%s_pmc_traffic.csv" % tag, "w") as f:
         f.write("\"%s\",%s,%d,%.1f,%.0f,%.1f,%.0f\n" % (k[0], k[1], fe[k][1], fk, 2 * fk * 1024, wk, tot))
 json.dump(traffic, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 
-# per kernel-family table in bench.py's naming ("family[batch=B]"): the family is read off the template arguments
-# (geometry + fragment pattern), the batch off the traffic (the smaller launch of a family is the acting batch)
-PATTERNS = [("conv1_fwd", "G84,84,4,20,20", "ap0"), ("conv1_wgrad", "G84,84,4,20,20", "ap1"),
-            ("conv2_fwd", "G20,20,", "ap0"), ("conv2_wgrad", "G20,20,", "ap1"),
-            ("conv3_fwd", "G9,9,64,7,7,1,0,0", "ap0"), ("conv3_wgrad", "G9,9,64,7,7,1,0,0", "ap1"),
+# per kernel-family table in bench.py's naming ("family[batch=B]"): dmm families are read off the template arguments
+# (geometry + fragment pattern; the smaller launch of a family is the acting batch), the fused kernels off their names
+PATTERNS = [("conv1_wgrad", "G84,84,4,20,20", "ap1"), ("conv2_wgrad", "G20,20,", "ap1"),
+            ("conv3_wgrad", "G9,9,64,7,7,1,0,0", "ap1"),
             ("fc_fwd", "G1,1,3136", "ap0"), ("fc_wgrad", "G1,1,3136", "ap1"), ("fc_dgrad", "G1,1,512", "ap0"),
+            ("conv1_fwd", "G84,84,4,20,20", "ap0"), ("conv2_fwd", "G20,20,", "ap0"), ("conv3_fwd", "G9,9,64,7,7,1,0,0", "ap0"),
             ("conv3_dgrad", "G7,7,64,9,9", "ap0"), ("conv2_dgrad", "G9,9,64,10,10", "ap0")]
 meta = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
 n_act, n_train = meta["config"]["envs_per_gpu"], meta["config"]["envs_per_gpu"] * meta["config"]["t_max"]
@@ -71,16 +71,33 @@ n_fwd = n_train + n_act       # the training forward carries the bootstrap rows
 fam = {}
 for name, gpat, ap in PATTERNS:
     ks = sorted([k for k in fe if gpat in k[0] and (" %s " % ap) in k[0]], key=lambda k: traffic["%s|%s" % k])
-    batches = [n_act, n_fwd] if len(ks) == 2 else ([n_train] if "grad" in name else [n_act])
+    if not ks:
+        continue
+    batches = [n_act, n_fwd] if len(ks) == 2 else ([n_train] if "grad" in name else [n_fwd if name.endswith("fwd") else n_act])
     for k, b in zip(ks, batches):
         fam["%s[batch=%d]" % (name, b)] = traffic["%s|%s" % k]
+FUSED = [("conv_tower", "tower_kernel<TowerGeom", None), ("fc_fwd", "fc_heads_kernel", n_act),
+         ("sample_env_step", "synth_step_a_mth_kernel", n_act), ("sample_env_step", "synth_step_a_mt_kernel", n_act),
+         ("conv3_dgrad", "dgrad_tower_kernel", n_train), ("heads_fwd", "heads_fwd_kernel", n_fwd),
+         ("heads_bwd", "heads_bwd_kernel", n_train), ("grad_finalize", "grad_finalize_kernel", n_train),
+         ("nstep_returns", "nstep_returns_kernel", n_train)]
+for name, pat, b in FUSED:
+    ks = sorted([k for k in fe if pat in k[0]], key=lambda k: traffic["%s|%s" % k])
+    if name == "conv_tower":           # acting regions variant (smaller traffic) and whole-sample training variant
+        for k, bb in zip(ks, [n_act, n_fwd]):
+            fam["conv_tower[batch=%d]" % bb] = traffic["%s|%s" % k]
+    elif ks:
+        fam["%s[batch=%d]" % (name, b)] = traffic["%s|%s" % ks[-1]]
+rk = [k for k in fe if "rmsprop_kernel" in k[0] or "sumsq_kernel" in k[0]]
+if rk:
+    fam["clip_rmsprop[batch=%d]" % 0] = sum(traffic["%s|%s" % k] for k in rk)
 json.dump({"workload": meta["config"]["workload"], "bytes_per_launch": fam,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                      "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B); average per launch"},
           open("profiles/%s_traffic_by_family.json" % tag, "w"), indent=1)
 
 # 3. bench lines + tuner log
-for name in ("bench_default.json", "bench_philox.json", "tune_gemm.txt"):
+for name in sorted(os.path.basename(f) for f in glob.glob(os.path.join(src, "bench_*.json"))) + ["tune_gemm.txt"]:
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, "profiles/%s_%s" % (tag, name))
