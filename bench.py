@@ -87,7 +87,7 @@ def time_host_plugin_loop(a, train, PAACLearner, np, cycles=60, warm=10):
     `warm` (per step: N x 28 KB observations H2D, one sync'ing D2H of the action indices, eager kernel launches)."""
     args = train.get_arg_parser().parse_args([])
     args.game, args.arch = a.game, a.arch
-    args.emulator_counts, args.max_local_steps, args.emulator_workers = a.envs, a.tmax, 0
+    args.emulator_counts, args.max_local_steps, args.emulator_workers = a.envs, a.tmax, 8    # the reference's default: 8 workers
     args.host_environments, args.metrics = True, False
     args.max_global_steps = cycles * a.envs * a.tmax
     args.debugging_folder = tempfile.mkdtemp(prefix="paac_bench_host_")
@@ -100,8 +100,9 @@ def time_host_plugin_loop(a, train, PAACLearner, np, cycles=60, warm=10):
     learner.train()
     dt = stamps[-1] - stamps[warm - 1]
     return dict(value=round((cycles - warm) * a.envs * a.tmax / dt, 1), unit="env-steps/s", cycles=cycles - warm,
-                note="host BaseEnvironment plugins stepped in-process (synthetic, numpy), observations H2D and actions "
-                     "D2H every step, eager launches; PCIe-inclusive, not `value`")
+                note="host BaseEnvironment plugins (synthetic, numpy) stepped by 8 worker processes through shared memory "
+                     "like the reference's runners, observations H2D (page-locked shared array) and actions D2H every step, "
+                     "eager launches; PCIe-inclusive, not `value`")
 
 
 def main():

@@ -391,6 +391,16 @@ def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_th
         "paac_sample_mt_synth_step")
 
 
+def pin_host_array(t):
+    """Page-lock the memory of a CPU tensor in place (hipHostRegister through torch's runtime handle) so that copies to
+    the device are asynchronous DMAs.  Returns True when the registration succeeded; a failure only costs speed."""
+    try:
+        rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+        return int(rc) == 0
+    except Exception:
+        return False
+
+
 class Graph(object):
     """hipGraph captured from the launches issued on torch's current stream between begin() and end()."""
 

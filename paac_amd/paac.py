@@ -457,7 +457,11 @@ class PAACLearner(ActorLearner):
             self.runners = Runners(EmulatorRunner, self.emulators, self.workers, variables)
             self.runners.start()
             shared_states, shared_rewards, shared_episode_over, shared_actions = self.runners.get_shared_variables()
-            current_states = lambda: torch.from_numpy(shared_states)
+            host_states = torch.from_numpy(shared_states)
+            # page-lock the shared observation array in place: the per-step H2D is then one DMA straight out of the
+            # memory the emulator workers write, instead of a staged pageable copy
+            pinned = hip_ops.pin_host_array(host_states)
+            current_states = lambda: host_states
 
         emulator_steps = [0] * N
         total_episode_rewards = N * [0]
@@ -483,7 +487,7 @@ class PAACLearner(ActorLearner):
         while self.global_step < self.max_global_steps and not parallel.any_rank(self.stop_requested, dev):
             loop_start_time = time.time()
             for t in range(T):
-                d_states[t].copy_(current_states())
+                d_states[t].copy_(current_states(), non_blocking=True)
                 self.ctx.forward(params, d_states[t], probs=d_probs, values=d_values[t])
                 hip_ops.sample_mt(d_probs, mt_state, mt_scratch, d_actions[t])
                 idx = d_actions[t].cpu().numpy()
