@@ -204,6 +204,33 @@ def test_checkpoint_roundtrip():
         assert np.array_equal(r1[k], r2[k]) and not np.all(r1[k] == 1.0)
 
 
+def test_cleanup_right_after_async_cycles_saves_a_consistent_checkpoint():
+    """cleanup() (what the signal handler ends in) straight after run_cycles(), with graph-replayed cycles still in
+    flight on the rollout's own stream: the checkpoint must hold the weights and optimizer slots of the LAST finished
+    update -- save_vars synchronises the rollout stream first."""
+    from paac_amd.paac import DeviceRollout
+    from paac_amd.session import Saver, checkpoint_key
+    import os
+    args = make_args(game="breakout", arch="NATURE", emulator_counts=8, emulator_workers=0, max_local_steps=5,
+                     max_global_steps=1 << 40, synthetic_terminal_p=0.05)
+    learner, _, env_creator = build_learner(args)
+    learner.global_step = learner.init_network()
+    learner.rollout = DeviceRollout(learner, env_creator.device_env_spec, sampler="philox", use_graph=True)
+    learner.rollout.run_cycles(24)                 # asynchronous: returns while the GPU is still replaying
+    learner.global_step += 24 * 40
+    learner.cleanup()                              # no explicit synchronize before it
+    torch.cuda.synchronize()
+    want = learner.network.get_parameters()
+    want_rms = learner.network.get_parameters(learner.rms)
+    with np.load(Saver.latest_checkpoint(os.path.join(args.debugging_folder, "checkpoints"))) as z:
+        for k, v in want.items():
+            assert np.array_equal(z[checkpoint_key("local_learning", k)], v), k
+    with np.load(Saver.latest_checkpoint(os.path.join(args.debugging_folder, "optimizer_checkpoints"))) as z:
+        for k, v in want_rms.items():
+            assert np.array_equal(z[checkpoint_key("local_learning", k, "OptimizerVariables")], v), k
+        assert not np.all(z[checkpoint_key("local_learning", "fc4_weights", "OptimizerVariables")] == 1.0)
+
+
 def test_cpu_device_is_rejected():
     args = make_args(device="/cpu:0", emulator_counts=2)
     with pytest.raises(RuntimeError):
