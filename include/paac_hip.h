@@ -105,7 +105,7 @@ int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states
  * environment on the MT19937 state, advanced in place) and steps the synthetic environments like paac_synth_step
  * (stack_out = shifted stacks with the new frame, stack_out2 (nullable) = a second copy of them; rewards / masks /
  * episode bookkeeping).
- * Requires N <= PAAC_ACT_STEP_MAX_ENVS and N*(A-1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS. */
+ * Requires N <= PAAC_ACT_STEP_MAX_ENVS and N*(A-1) <= 1024. */
 #define PAAC_ACT_STEP_MAX_ENVS 64
 int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
@@ -215,8 +215,9 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
 
 /* paac_sample_mt + paac_synth_step (path A) in ONE launch: workgroup 0 samples (numpy-parity MT19937 stream) and does
  * the per-env bookkeeping while the other workgroups shift the observation stacks (stack_out2, nullable: a second copy
- * of the new stacks, like paac_synth_step's).  Limit: N*(A-1) <= 1024. */
-#define PAAC_FUSED_SAMPLE_MAX_DRAWS 1024
+ * of the new stacks, like paac_synth_step's).  Limit: N*(A-1) <= 2304 (covers 256 environments x 4 actions and
+ * 128 x 18). */
+#define PAAC_FUSED_SAMPLE_MAX_DRAWS 2304
 int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
                               uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,

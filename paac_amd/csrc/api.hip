@@ -282,9 +282,9 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
                masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS,
                "paac_act_step_mt: batch %d outside (0, min(max_batch=%d, %d)]", batch, ctx->max_batch, PAAC_ACT_STEP_MAX_ENVS);
-  PAAC_REQUIRE((int64_t)batch * (ctx->cfg.num_actions - 1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS,
-               "paac_act_step_mt: N*(A-1) = %ld exceeds %d (use paac_forward + paac_sample_mt + paac_synth_step)",
-               (long)batch * (ctx->cfg.num_actions - 1), PAAC_FUSED_SAMPLE_MAX_DRAWS);
+  PAAC_REQUIRE((int64_t)batch * (ctx->cfg.num_actions - 1) <= 1024,
+               "paac_act_step_mt: N*(A-1) = %ld exceeds 1024 (use paac_forward + paac_sample_mt_synth_step)",
+               (long)batch * (ctx->cfg.num_actions - 1));
   PAAC_REQUIRE(states != stack_out && states != stack_out2, "paac_act_step_mt: the step cannot shift the stacks in place");
   const float *partial, *ba, *bc;
   int ntiles;

@@ -156,10 +156,17 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
 }
 
 // scratch layout (bytes): pj f64[N*(A-1)] | U f64[N*(A-1)] | blocks u32[nblk*624]
-// LDSPATH (N*(A-1) <= 1024): the three work arrays live in LDS instead of the global scratch.
-constexpr int MT_LDS_D = 1024;
-constexpr int MT_LDS_BLK = 5;   // 624 + 2*1024 u32 <= 5*624
-constexpr int MT_TAB_MAX = 16384;
+// LDSC > 0 (N*(A-1) <= mt_lds_d(LDSC)): the three work arrays live in LDS instead of the global scratch.
+// LDS size classes of the sampler body: 0 = work arrays in the global scratch, 1 = small (the 32..64-environment shards),
+// 2 = large (256 environments x 4 actions, 128 x 18: one workgroup with most of the CU's LDS)
+constexpr int MT_LDS_D = 1024;            // class 1: draws (N * (A - 1)) the LDS arrays hold
+constexpr int MT_LDS_D2 = 2304;           // class 2
+constexpr int MT_TAB_MAX = 16384;         // class 1: entries of the first-hit table
+constexpr int MT_TAB_MAX2 = 66560;        // class 2: 256 environments x 3 draws -> 65,536 + 256 entries
+__host__ __device__ constexpr int mt_lds_d(int cls) { return cls == 2 ? MT_LDS_D2 : (cls == 1 ? MT_LDS_D : 1); }
+__host__ __device__ constexpr int mt_lds_blk(int cls) { return cls == 0 ? 1 : (624 + 2 * mt_lds_d(cls)) / 624 + 2; }
+__host__ __device__ constexpr int mt_tab_max(int cls) { return cls == 2 ? MT_TAB_MAX2 : (cls == 1 ? MT_TAB_MAX : 1); }
+__host__ __device__ constexpr int mt_skip_max(int cls) { return cls == 2 ? 4352 : (cls == 1 ? 1280 : 1); }
 // Phase 4a of sample_mt_body: jh(e, o) = first category hit when environment e starts drawing at stream offset o, for
 // every reachable (e, o).  Environment e has e (J-1) + 1 reachable offsets (every earlier environment drew between 1
 // and J doubles), so e is paired with N-1-e -- every pair has (N-1)(J-1) + 2 entries -- and each pair is filled by one
@@ -191,23 +198,46 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
         threshold(eb, j, thr_b[j], inv_b[j]);
       }
     }
+    if constexpr (JC > 0) {
+      // four entries per iteration, every draw of all four requested before the first compare (the loop is LDS-latency
+      // bound: one entry at a time spends ~400 cycles per entry, 256 entries per thread at 256 environments)
+      constexpr int UNR = 4;
+      const int total = cnt_a + cnt_b;
+      for (int c0 = k; c0 < total; c0 += 16 * UNR) {
+        double U[UNR][JR];
+        bool first[UNR], live[UNR];
+        int idx[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int c = c0 + 16 * u;
+          live[u] = c < total;
+          first[u] = c < cnt_a;
+          idx[u] = first[u] ? c : c - cnt_a;
+          const int o = (first[u] ? ea : eb) + (live[u] ? idx[u] : 0);
+#pragma unroll
+          for (int j = 0; j < JC; ++j) U[u][j] = u_buf[o + j < D ? o + j : D - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          int jh = J;
+#pragma unroll
+          for (int j = JC - 1; j >= 0; --j) {
+            const double thr = first[u] ? thr_a[j] : thr_b[j];
+            const bool inv = first[u] ? inv_a[j] : inv_b[j];
+            if ((U[u][j] > thr) != inv) jh = j;
+          }
+          if (live[u]) jh_tab[(first[u] ? base_a : base_b) + idx[u]] = (unsigned char)jh;
+        }
+      }
+      continue;
+    }
     for (int c = k; c < cnt_a + cnt_b; c += 16) {
       const bool first = c < cnt_a;
       const int e = first ? ea : eb;
       const int idx = first ? c : c - cnt_a;   // table slot of the pair member
       const int o = e + idx;                   // stream offset it stands for
       int jh = J;
-      if constexpr (JC > 0) {
-        double U[JR];
-#pragma unroll
-        for (int j = 0; j < JC; ++j) U[j] = u_buf[o + j < D ? o + j : D - 1];
-#pragma unroll
-        for (int j = JC - 1; j >= 0; --j) {
-          const double thr = first ? thr_a[j] : thr_b[j];
-          const bool inv = first ? inv_a[j] : inv_b[j];
-          if ((U[j] > thr) != inv) jh = j;
-        }
-      } else {
+      {
         for (int j = J - 1; j >= 0; --j) {
           double thr;
           bool inv;
@@ -220,25 +250,27 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
   }
 }
 
-// probs_lds (LDSPATH only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
+// probs_lds (LDSC > 0 only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
 // stw_pre (with probs_lds): the caller requested the 625 state words (3 per thread, clamped index) before producing them.
-template <bool LDSPATH>
+template <int LDSC>
 __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
                                                double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
-                                               int32_t* __restrict__ actions, int32_t* act_lds,
+                                               int32_t* __restrict__ actions, int16_t* act_lds,
                                                const float* probs_lds = nullptr, const uint32_t* stw_pre = nullptr) {
   MISC_STAMP(0);
-  __shared__ double pj_s[LDSPATH ? MT_LDS_D : 1];
-  __shared__ double u_s[LDSPATH ? MT_LDS_D : 1];
-  __shared__ uint32_t blocks_s[LDSPATH ? MT_LDS_BLK * 624 : 1];
+  constexpr bool LDSPATH = LDSC > 0;
+  constexpr int PRW = LDSC == 2 ? 18 : 8;             // probability floats per thread of the one-round-trip load
+  __shared__ double pj_s[mt_lds_d(LDSC)];
+  __shared__ double u_s[mt_lds_d(LDSC)];
+  __shared__ uint32_t blocks_s[mt_lds_blk(LDSC) * 624];
   double* pj_buf = LDSPATH ? pj_s : pj_g;
   double* u_buf = LDSPATH ? u_s : u_g;
   uint32_t* blocks = LDSPATH ? blocks_s : blocks_g;
   const int tid = threadIdx.x;
   const int J = A - 1;
   const int D = N * J;
-  __shared__ float probs_s[LDSPATH ? 2 * MT_LDS_D : 1];   // N*A = D*A/(A-1) <= 2*D floats
+  __shared__ float probs_s[LDSPATH ? 2 * mt_lds_d(LDSC) : 1];   // N*A = D*A/(A-1) <= 2*D floats
   __shared__ uint32_t pos_s;
   __shared__ int any_zero;       // some conditional probability is exactly 0 (the table chase needs none); later
                                  // reused for the consumed-draw count
@@ -248,12 +280,12 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     // ONE memory round trip: the 625 state words and the N*A probabilities are all requested before anything
     // is consumed (unrolled, clamped indices), then parked in LDS.
     uint32_t stw[3];
-    float prw[8];
+    float prw[PRW];
 #pragma unroll
     for (int k = 0; k < 3; ++k) stw[k] = stw_pre ? stw_pre[k] : mt_state[min(tid + k * 256, 624)];
     if (!probs_lds) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) prw[k] = probs[min(tid + k * 256, N * A - 1)];
+      for (int k = 0; k < PRW; ++k) prw[k] = probs[min(tid + k * 256, N * A - 1)];
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -263,7 +295,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     }
     if (!probs_lds) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < PRW; ++k)
         if (tid + k * 256 < N * A) probs_s[tid + k * 256] = prw[k];
     }
     __syncthreads();
@@ -319,12 +351,14 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   // o + min(jh+1, J) with jh = first category hit when env e starts drawing at offset o.  jh is tabulated for
   // every reachable (e, o) in parallel (o <= e*J), then one lane chases the table: N dependent LDS byte reads
   // instead of N ballot/popcount/compare rounds.
-  __shared__ unsigned char jh_tab[LDSPATH ? MT_TAB_MAX : 1];
+  __shared__ unsigned char jh_tab[mt_tab_max(LDSC)];
+  __shared__ unsigned short skip_tab[mt_skip_max(LDSC)];
+  __shared__ int entry_s[33];
   bool chased = false;
   if constexpr (LDSPATH) {
     // env e can only start at offsets e .. e J (every earlier env drew between 1 and J doubles)
     const long tab_entries = (long)N + (long)(J - 1) * N * (N - 1) / 2;
-    if (tab_entries <= MT_TAB_MAX && N <= 256) {
+    if (tab_entries <= mt_tab_max(LDSC) && N <= 256) {
       if (!any_zero) {     // set in phase 1, visible since the barrier after phase 3
         // Table fill (mt_fill_table): the category count is dispatched to a compile-time constant, so the fill has
         // no branch per category
@@ -341,18 +375,85 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
         }
         __syncthreads();
         MISC_STAMP(5);
-        if (tid == 0) {
-          int o = 0, base = 0, ej = 0;               // base(e) - e = (J-1) e (e-1)/2, ej = e (J-1)
-          for (int e = 0; e < N; ++e) {
-            const int jh = jh_tab[base + o];         // slot base(e) + (o - e)
-            actions[e] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
-            if (act_lds) act_lds[e] = jh;
-            o += (jh + 1 < J) ? jh + 1 : J;
-            base += ej;
-            ej += J - 1;
+        constexpr int G = 16;                           // environments per group of the two-level chase
+        constexpr int MAXQ = (mt_skip_max(LDSC) / 8 + 31) / 32 + 1;   // walks per thread there (a pair of groups per 32 threads)
+        const int NG = (N + G - 1) / G;
+        const int c1 = J - 1, cg = G * (J - 1);
+        const bool two_level = N > 64 && (NG - 1) * cg + 2 <= 32 * MAXQ && NG + cg * (NG * (NG - 1) / 2) <= mt_skip_max(LDSC);
+        if (!two_level) {
+          // one lane hops through the table: N dependent LDS byte reads
+          if (tid == 0) {
+            int o = 0, base = 0, ej = 0;               // base(e) - e = (J-1) e (e-1)/2, ej = e (J-1)
+            for (int e = 0; e < N; ++e) {
+              const int jh = jh_tab[base + o];         // slot base(e) + (o - e)
+              actions[e] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
+              if (act_lds) act_lds[e] = (int16_t)jh;
+              o += (jh + 1 < J) ? jh + 1 : J;
+              base += ej;
+              ej += J - 1;
+            }
+            any_zero = o;                                 // reuse as the consumed-draw count
           }
-          jh_tab[0] = 0;
-          any_zero = o;                                 // reuse as the consumed-draw count
+        } else {
+          // Two-level chase.  The stream offset after environment e is a function of the offset before it; environments are
+          // cut into groups of G = 16, and for every group and every offset it can be entered at, the offset it is left at
+          // is tabulated first: independent walks, each thread advancing its ~16 walks hop by hop without a branch so
+          // that their table reads overlap (group k is paired with NG-1-k: every pair has the same number of entries).
+          // Then one lane hops over the groups (N / 16 dependent reads instead of N) and one thread per group replays its
+          // 16 environments from the true entry offset to emit the actions.
+          auto tab_base = [&](const int e) { return e + c1 * (e * (e - 1) / 2); };      // slot of (e, o) = tab_base(e) + o - e
+          auto skip_base = [&](const int k) { return k + cg * (k * (k - 1) / 2); };     // group k: entry offsets kG .. kGJ
+          const int pr = tid >> 5, ln = tid & 31;         // 8 pairs of groups per pass
+          for (int p0 = 0; p0 < (NG + 1) / 2; p0 += 8) {
+            const int ka = p0 + pr, kb = NG - 1 - ka;
+            const bool pair_ok = ka <= kb;
+            const int cnt_a = pair_ok ? ka * cg + 1 : 0, cnt_b = (pair_ok && kb != ka) ? kb * cg + 1 : 0;
+            int wo[MAXQ], we[MAXQ], wb[MAXQ], ws[MAXQ];    // offset, environment, table base of it, skip slot (-1: none)
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+              const int c = ln + 32 * q;
+              const bool live = c < cnt_a + cnt_b, first = c < cnt_a;
+              const int k = first ? ka : kb, idx = first ? c : c - cnt_a;
+              we[q] = live ? k * G : 0;
+              wo[q] = we[q] + (live ? idx : 0);
+              wb[q] = tab_base(we[q]);
+              ws[q] = live ? skip_base(k) + idx : -1;
+            }
+            for (int hop = 0; hop < G; ++hop) {
+#pragma unroll
+              for (int q = 0; q < MAXQ; ++q) {
+                const bool ok = ws[q] >= 0 && we[q] < N;
+                const int jh = jh_tab[ok ? wb[q] + wo[q] - we[q] : 0];
+                const int st = (jh + 1 < J) ? jh + 1 : J;
+                wo[q] += ok ? st : 0;
+                wb[q] += 1 + c1 * we[q];                  // tab_base(e + 1) - tab_base(e)
+                we[q] += 1;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q)
+              if (ws[q] >= 0) skip_tab[ws[q]] = (unsigned short)wo[q];
+          }
+          __syncthreads();
+          if (tid == 0) {
+            int o = 0;
+            for (int k = 0; k < NG; ++k) {
+              entry_s[k] = o;
+              o = skip_tab[skip_base(k) + o - k * G];
+            }
+            any_zero = o;                                 // reuse as the consumed-draw count
+          }
+          __syncthreads();
+          if (tid < NG) {
+            int o = entry_s[tid];
+            const int e1 = min(N, tid * G + G);
+            for (int e = tid * G; e < e1; ++e) {
+              const int jh = jh_tab[tab_base(e) + o - e];
+              actions[e] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
+              if (act_lds) act_lds[e] = (int16_t)jh;
+              o += (jh + 1 < J) ? jh + 1 : J;
+            }
+          }
         }
         __syncthreads();
         chased = true;
@@ -391,7 +492,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
       }
       if (lane == 0) {
         actions[e] = act;
-        if (act_lds) act_lds[e] = act;
+        if (act_lds) act_lds[e] = (int16_t)act;
       }
       o += used;
     }
@@ -409,12 +510,12 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   }
 }
 
-template <bool LDSPATH>
+template <int LDSC>
 __global__ __launch_bounds__(256) void sample_mt_kernel(const float* __restrict__ probs, int N, int A,
                                                         uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
                                                         double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
                                                         int32_t* __restrict__ actions) {
-  sample_mt_body<LDSPATH>(probs, N, A, mt_state, pj_g, u_g, blocks_g, actions, nullptr);
+  sample_mt_body<LDSC>(probs, N, A, mt_state, pj_g, u_g, blocks_g, actions, nullptr);
 }
 
 // =============================================================================================
@@ -539,7 +640,10 @@ __global__ __launch_bounds__(256) void synth_step_a_kernel(uint64_t seed, uint32
 // Path A with the numpy-parity sampler folded in: workgroup 0 runs the (inherently serial) MT19937 sampler and then
 // the per-env bookkeeping, the other N*7 workgroups shift the observation stacks meanwhile -- the new frame and the
 // terminal flag of the synthetic environments do not depend on the action, only reward bookkeeping does.  One launch
-// per time step instead of two.
+// per time step instead of two.  LDSC = 2 (large shards: up to 2304 draws): the sampler workgroup takes most of a CU's LDS,
+// which every workgroup of the launch then reserves -- so the stacks are shifted by one workgroup per environment (all 7
+// bands) instead of one per band.
+template <int LDSC>
 __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __restrict__ probs, int A,
                                                               uint32_t* __restrict__ mt_state,
                                                               int32_t* __restrict__ actions, uint64_t seed,
@@ -552,12 +656,12 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
                                                               FinishedRing* fin) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   if (blockIdx.x == 0) {
-    __shared__ int32_t act_s[MT_LDS_D];
+    __shared__ int16_t act_s[mt_lds_d(LDSC)];
     // the running episode totals do not depend on the sampler: request them before it (first 256 environments)
     const int e0 = threadIdx.x < N ? threadIdx.x : 0;
     const float ep_reward0 = ep_reward[e0];
     const int32_t ep_len0 = ep_len[e0];
-    sample_mt_body<true>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);
+    sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);
     __syncthreads();
     MISC_STAMP(7);
     for (int e = threadIdx.x; e < N; e += 256) {
@@ -565,12 +669,17 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
       if (e < 256)
         synth_bookkeep_with(key, e, act_s[e], thresh, ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
       else
-        synth_bookkeep(key, e, act_s, thresh, rewards_out, masks_out, ep_reward, ep_len, fin);
+        synth_bookkeep_with(key, e, act_s[e], thresh, ep_reward[e], ep_len[e], rewards_out, masks_out, ep_reward, ep_len, fin);
     }
     MISC_STAMP(8);
     return;
   }
-  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
+  if constexpr (LDSC == 2) {
+    for (int band = 0; band < PRE_BANDS; ++band)
+      synth_shift_band(seed, env_offset, id, thresh, ((int)blockIdx.x - 1) * PRE_BANDS + band, stack_in, stack_out, stack_out2);
+  } else {
+    synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
+  }
 }
 
 // The same launch with the heads finish in front of the sampler: workgroup 0 sums the fc kernel's per-tile head partials
@@ -590,7 +699,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
                                                                FinishedRing* fin) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   if (blockIdx.x == 0) {
-    __shared__ int32_t act_s[kFcHeadsMaxRows];
+    __shared__ int16_t act_s[kFcHeadsMaxRows];
     __shared__ float lg_s[kFcHeadsMaxRows * 33];
     __shared__ float probs_sh[kFcHeadsMaxRows * 32];
     // nothing below depends on these: request them before the head sums
@@ -602,7 +711,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
     const int32_t ep_len0 = ep_len[e0];
     heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,
                         nullptr);
-    sample_mt_body<true>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
+    sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
     __syncthreads();
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
@@ -1090,10 +1199,13 @@ int paac_sample_mt(const float* probs, int N, int A, uint32_t* mt_state, void* s
   uint32_t* blocks = (uint32_t*)(u + D);
   ProfScope ps(g_prof_ctx, F_SAMPLE_MT, N, (hipStream_t)stream);
   if (D <= MT_LDS_D)
-    launch_k(sample_mt_kernel<true>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
+    launch_k(sample_mt_kernel<1>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
+             blocks, actions);
+  else if (D <= MT_LDS_D2)
+    launch_k(sample_mt_kernel<2>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
              blocks, actions);
   else
-    launch_k(sample_mt_kernel<false>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
+    launch_k(sample_mt_kernel<0>, dim3(1), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, N, A, mt_state, pj, u,
              blocks, actions);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1174,14 +1286,22 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
                               paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
-  PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
-               "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D);
+  PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D2, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
+               "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D2);
   PAAC_REQUIRE(probs && mt_state && actions && stack_in && stack_out && rewards_out && masks_out && ep_reward && ep_len,
                "paac_sample_mt_synth_step: null argument");
   ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, (hipStream_t)stream);
-  launch_k(synth_step_a_mt_kernel, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
-           actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
-           (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
+  // small shards: the small-LDS sampler, one shift workgroup per band; beyond 1024 draws or 64 environments (where the
+  // two-level chase needs the large first-hit table): the large-LDS sampler, one shift workgroup per environment
+  const bool large = (int64_t)N * (A - 1) > MT_LDS_D || (long)N + (long)(A - 2) * N * (N - 1) / 2 > MT_TAB_MAX;
+  if (large)
+    launch_k(synth_step_a_mt_kernel<2>, dim3(1 + N), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
+             actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
+  else
+    launch_k(synth_step_a_mt_kernel<1>, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
+             actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

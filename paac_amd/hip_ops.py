@@ -168,8 +168,8 @@ class Context(object):
         """One acting step in three launches: policy forward, then heads finish + numpy-parity sampler + synthetic
         environment step in one (include/paac_hip.h: paac_act_step_mt)."""
         N, A = self._check_states(states), self.num_actions
-        if N > ACT_STEP_MAX_ENVS or N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
-            raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS, FUSED_SAMPLE_MAX_DRAWS))
+        if N > ACT_STEP_MAX_ENVS or N * (A - 1) > ACT_STEP_MAX_DRAWS:
+            raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS, ACT_STEP_MAX_DRAWS))
         if tuple(stack_out.shape) != (N,) + OBS_SHAPE:
             raise ValueError("stack_out must be [%d,84,84,4], got %s" % (N, tuple(stack_out.shape)))
         if states.data_ptr() == stack_out.data_ptr() or (stack_out2 is not None and states.data_ptr() == stack_out2.data_ptr()):
@@ -365,7 +365,8 @@ def synth_step(seed, env_offset, actions, terminal_threshold, step_base_dev, ste
                                            _stream()), "paac_synth_step")
 
 
-FUSED_SAMPLE_MAX_DRAWS = 1024
+FUSED_SAMPLE_MAX_DRAWS = 2304
+ACT_STEP_MAX_DRAWS = 1024
 ACT_STEP_MAX_ENVS = 64
 
 

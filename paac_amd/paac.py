@@ -101,7 +101,7 @@ class DeviceRollout(object):
             # the ring wraps after an odd cycle: its last step also writes slot 0 (the next even cycle's first slot)
             wrap = self.states[0] if (parity == 1 and t == T - 1) else None
             fused = self.sampler == "numpy" and self.raw is None and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS
-            if fused and N <= hip_ops.ACT_STEP_MAX_ENVS:
+            if fused and N <= hip_ops.ACT_STEP_MAX_ENVS and N * (self.A - 1) <= hip_ops.ACT_STEP_MAX_DRAWS:
                 # the whole step in three launches: conv tower, fc + head partials, heads finish + sampler + env step
                 L.ctx.act_step_mt(params, st[t], self.mt_state, self.actions[t], self.probs, self.values[t],
                                   self.env_spec["seed"], self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,

@@ -69,7 +69,8 @@ def test_golden_returns_and_sampler(path):
         assert np.array_equal(adv.cpu().numpy(), g["adv"][c].astype(np.float32))
 
 
-@pytest.mark.parametrize("N,A", [(32, 4), (8, 6), (16, 18), (256, 4), (1024, 18), (3, 2), (5, 32)])
+@pytest.mark.parametrize("N,A", [(32, 4), (8, 6), (16, 18), (256, 4), (1024, 18), (3, 2), (5, 32),
+                                 (64, 4), (65, 4), (100, 6), (128, 18), (255, 3), (33, 9)])
 def test_sampler_mt_matches_numpy(N, A):
     from paac_amd import hip_ops
     gen = np.random.RandomState(N * 31 + A)
@@ -311,3 +312,53 @@ def test_act_step_equals_separate_calls(arch, A, N, managed):
     assert np.abs(a["probs"].cpu().numpy() - ref["pi"]).max() < 1e-5
     assert np.abs(a["val"].cpu().numpy() - ref["v"]).max() < 1e-4
     ctx.close()
+
+
+@pytest.mark.parametrize("N,A", [(32, 4), (256, 4), (128, 18), (96, 6)])
+def test_fused_sampler_env_step_equals_separate_calls(N, A):
+    """paac_sample_mt_synth_step (small and large-LDS variants: 256 environments x 4 actions = two-level table chase with
+    one shift workgroup per environment; 128 x 18 = lane walk) == paac_sample_mt + paac_synth_step, bit for bit, and the
+    actions are numpy's."""
+    from paac_amd import hip_ops
+    from paac_amd.synthetic import terminal_threshold
+    env_seed, off, thr = 9, 2, terminal_threshold(0.2)
+    rs = np.random.RandomState(31)
+    gen = np.random.RandomState(N + A)
+
+    def fresh():
+        d = dict(s0=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 s1=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 s2=torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda"),
+                 act=torch.zeros(N, dtype=torch.int32, device="cuda"), rew=torch.zeros(N, device="cuda"),
+                 msk=torch.zeros(N, device="cuda"), ep_r=torch.zeros(N, device="cuda"),
+                 ep_l=torch.zeros(N, dtype=torch.int32, device="cuda"),
+                 fin=torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device="cuda"),
+                 tick=torch.zeros(1, dtype=torch.int64, device="cuda"),
+                 mt=hip_ops.mt_state_from_numpy(rs.get_state(), "cuda"))
+        hip_ops.synth_reset(env_seed, off, d["s0"], None)
+        return d
+
+    a, b = fresh(), fresh()
+    ref_rs = np.random.RandomState(31)
+    scratch = hip_ops.sample_mt_scratch(N, A, "cuda")
+    for step in range(4):
+        logits = gen.randn(N, A) * 1.5
+        p = np.exp(logits - logits.max(1, keepdims=True))
+        p = np.maximum(p / p.sum(1, keepdims=True), 1e-6).astype(np.float32)
+        p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        pd = dev(p)
+        hip_ops.sample_mt_synth_step(pd, a["mt"], a["act"], env_seed, off, thr, a["tick"], 0, a["s0"], a["s1"], a["rew"],
+                                     a["msk"], a["ep_r"], a["ep_l"], a["fin"], stack_out2=a["s2"])
+        hip_ops.sample_mt(pd, b["mt"], scratch, b["act"])
+        hip_ops.synth_step(env_seed, off, b["act"], thr, b["tick"], 0, b["s0"], b["s1"], b["rew"], b["msk"], b["ep_r"],
+                           b["ep_l"], b["fin"], stack_out2=b["s2"])
+        torch.cuda.synchronize()
+        for k in ("act", "mt", "rew", "msk", "ep_r", "ep_l", "s1", "s2"):
+            assert torch.equal(a[k], b[k]), "step %d: %s differs" % (step, k)
+        assert torch.equal(a["s1"], a["s2"])
+        want = osamp.sample_numpy_reference(p, ref_rs)
+        assert np.array_equal(a["act"].cpu().numpy(), np.asarray(want, dtype=np.int32))
+        for d in (a, b):
+            hip_ops.counter_add(d["tick"], 1)
+            d["s0"], d["s1"] = d["s1"], d["s0"]
+    assert hip_ops.mt_state_to_numpy(a["mt"])[2] == ref_rs.get_state()[2]
