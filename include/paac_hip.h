@@ -135,6 +135,31 @@ int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states
                        const float* y, const float* adv, int batch, float entropy_beta,
                        float* grad, float* loss_out, int forward_done, int phase, paac_stream_t stream);
 
+/* paac_nstep_returns_tick + paac_loss_backward with the returns computed inside the backward's first launch (the heads
+ * gradient kernel derives y / adv of every row from the rollout records; its last workgroup writes y_out / adv_out and
+ * does the global_step / lr / frame-counter bookkeeping): one launch less per update, same values bit for bit.
+ * batch must equal T*N (rows t-major, paac.py:151-154).  With phase == 2 (conv part only) `ret` is not used. */
+typedef struct {
+  const float* v_boot;        /* [N] bootstrap values (float32 network output, paac.py:140-142) */
+  const float* rewards;       /* [T,N] clipped rewards */
+  const float* masks;         /* [T,N] 1 - terminal */
+  const float* values;        /* [T,N] values of the acting forwards */
+  int32_t T, N;
+  double gamma;
+  float* y_out;               /* [T*N] */
+  float* adv_out;             /* [T*N] */
+  int64_t* global_step_dev;   /* nullable: no schedule bookkeeping */
+  int64_t increment;
+  double initial_lr;
+  int64_t lr_annealing_steps;
+  float* lr_out_dev;
+  uint64_t* tick_dev;         /* nullable */
+  uint64_t tick_inc;
+} paac_returns;
+int paac_loss_backward_returns(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
+                               const paac_returns* ret, int batch, float entropy_beta, float* grad, float* loss_out,
+                               int forward_done, int phase, paac_stream_t stream);
+
 /* tf.clip_by_global_norm + RMSPropOptimizer.apply_gradients (actor_learner.py:31-34,56-59,70):
  *   g <- grad * grad_scale           (grad_scale = 1/world_size after the sum all-reduce)
  *   gn = sqrt(sum g^2); g <- g * clip_norm*min(1/gn, 1/clip_norm)  (mode GLOBAL)

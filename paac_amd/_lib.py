@@ -31,6 +31,14 @@ class Cfg(ctypes.Structure):
     _fields_ = [("device", c_int32), ("arch", c_int32), ("num_actions", c_int32), ("max_batch", c_int32)]
 
 
+class Returns(ctypes.Structure):
+    """paac_returns (include/paac_hip.h): the rollout records the fused returns + backward entry reads."""
+    _fields_ = [("v_boot", c_void_p), ("rewards", c_void_p), ("masks", c_void_p), ("values", c_void_p),
+                ("T", c_int32), ("N", c_int32), ("gamma", ctypes.c_double), ("y_out", c_void_p), ("adv_out", c_void_p),
+                ("global_step_dev", c_void_p), ("increment", c_int64), ("initial_lr", ctypes.c_double),
+                ("lr_annealing_steps", c_int64), ("lr_out_dev", c_void_p), ("tick_dev", c_void_p), ("tick_inc", c_uint64)]
+
+
 class PaacHipError(RuntimeError):
     pass
 
@@ -49,6 +57,8 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "paac_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "paac_set_managed_weights": (c_int, [c_void_p, c_int]),
+    "paac_loss_backward_returns": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Returns), c_int, c_float, c_void_p,
+                                           c_void_p, c_int, c_int, c_void_p]),
     "paac_grad_stats": (c_int, [c_void_p, c_void_p, c_void_p]),
     "paac_clip_rmsprop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float,
                                   c_float, c_float, c_float, c_int, c_float, c_void_p, c_void_p]),

@@ -319,6 +319,32 @@ int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states
   return 0;
 }
 
+int paac_loss_backward_returns(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
+                               const paac_returns* ret, int batch, float entropy_beta, float* grad, float* loss_out,
+                               int forward_done, int phase, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states && actions && ret && grad, "paac_loss_backward_returns: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_loss_backward_returns: batch %d outside (0, max_batch=%d]", batch,
+               ctx->max_batch);
+  PAAC_REQUIRE(phase >= 0 && phase <= 2, "paac_loss_backward_returns: phase %d", phase);
+  PAAC_REQUIRE(ret->T > 0 && ret->N > 0 && ret->T * ret->N == batch, "paac_loss_backward_returns: T*N = %d*%d != batch %d",
+               ret->T, ret->N, batch);
+  PAAC_REQUIRE(ret->v_boot && ret->rewards && ret->masks && ret->values && ret->y_out && ret->adv_out,
+               "paac_loss_backward_returns: null rollout record");
+  PAAC_REQUIRE(!ret->global_step_dev || (ret->lr_out_dev && ret->lr_annealing_steps > 0),
+               "paac_loss_backward_returns: schedule bookkeeping needs lr_out_dev and lr_annealing_steps");
+  int rc = 0;
+  if (!forward_done && phase != 2) {
+    rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  ctx->last_ws = 1;
+  rc = launch_backward(ctx, params, states, actions, ret->y_out, ret->adv_out, batch, entropy_beta, grad, loss_out, phase,
+                       (hipStream_t)stream, ret);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream) {
   PAAC_REQUIRE(ctx && out && batch > 0 && batch <= ctx->max_batch, "paac_debug_activation: bad arguments");
   const float* src = nullptr;

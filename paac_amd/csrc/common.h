@@ -176,6 +176,7 @@ int launch_sample_env_step_heads(const float* partial, int ntiles, const float* 
                                  const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
                                  float* masks, float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
-                    const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s);
+                    const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s,
+                    const paac_returns* ret = nullptr);
 
 }  // namespace paac

@@ -243,15 +243,63 @@ __device__ __forceinline__ void head_grad_row(const float (&pi)[AP], float v, in
   }
 }
 
+// The n-step returns of the rollout (paac.py:140-149) computed where they are consumed: with v_boot set, the heads
+// gradient launch derives y / adv of a row itself from the rollout records (every consumer recomputes the short scan:
+// cheaper than a launch of its own), its last block writes the y / adv arrays for the learner's records and does the
+// per-cycle bookkeeping of paac_nstep_returns_tick (global_step, lr, frame counter).  Arithmetic = nstep_returns_kernel's
+// (csrc/misc.hip), operation for operation.
+struct ReturnsArgs {
+  const float* v_boot;      // nullptr: y / adv are read from the arrays passed to the kernel
+  const float* rewards;     // [T,N] clipped
+  const float* masks;       // [T,N]
+  const float* values_act;  // [T,N] values of the acting forwards
+  int T, N;
+  double gamma;
+  float* y_out;             // [T*N] t-major, written by the last block
+  float* adv_out;
+  int64_t* global_step;     // += step_inc, then lr = f32(lr0 - step*lr0/anneal)   (actor_learner.py:119-123); nullable
+  int64_t step_inc;
+  double lr0;
+  int64_t anneal;
+  float* lr_out;
+  uint64_t* tick;           // += tick_inc; nullable
+  uint64_t tick_inc;
+};
+
+__device__ __forceinline__ void nstep_row(const ReturnsArgs& r, const int i, float& y, float& adv) {
+  const int t = i / r.N, e = i - t * r.N;
+  const float vb = r.v_boot[e];
+  double R = 0.0;
+  for (int tt = r.T - 1; tt >= t; --tt) {
+    const long k = (long)tt * r.N + e;
+    const double prod = (tt == r.T - 1) ? (double)__fmul_rn((float)r.gamma, vb) : __dmul_rn(r.gamma, R);
+    R = __dadd_rn((double)r.rewards[k], __dmul_rn(prod, (double)r.masks[k]));
+  }
+  y = (float)R;
+  adv = (float)__dsub_rn(R, (double)r.values_act[(long)t * r.N + e]);
+}
+
 template <int AP>
 __device__ __forceinline__ void load_row_and_grad(const float* __restrict__ probs, const float* __restrict__ values,
                                                   const int32_t* __restrict__ actions, const float* __restrict__ y,
                                                   const float* __restrict__ adv, int i, int A, float beta, float s,
-                                                  float (&out)[AP + 1], float* stats) {
+                                                  float (&out)[AP + 1], float* stats, const ReturnsArgs& rt,
+                                                  float* yv_out = nullptr, float* av_out = nullptr) {
   float pi[AP];
 #pragma unroll
   for (int a = 0; a < AP; ++a) pi[a] = probs[(long)i * A + (a < A ? a : 0)];
-  head_grad_row<AP>(pi, values[i], actions[i], y[i], adv[i], beta, s, A, out, stats);
+  float yv, av;
+  if (rt.v_boot) {
+    nstep_row(rt, i, yv, av);
+  } else {
+    yv = y[i];
+    av = adv[i];
+  }
+  if (yv_out) {
+    *yv_out = yv;
+    *av_out = av;
+  }
+  head_grad_row<AP>(pi, values[i], actions[i], yv, av, beta, s, A, out, stats);
 }
 
 // One launch, three roles by blockIdx:
@@ -268,7 +316,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                                                         int A, int B, float beta, float* __restrict__ dH,
                                                         float* __restrict__ gWa, float* __restrict__ gba,
                                                         float* __restrict__ gWc, float* __restrict__ gbc,
-                                                        float* __restrict__ loss_out) {
+                                                        float* __restrict__ loss_out, const ReturnsArgs rt) {
   constexpr int NV = AP + 1;
   constexpr int NS = NV + 3;                       // + 3 loss statistics (role 3)
   const int tid = threadIdx.x;
@@ -291,7 +339,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
       for (int a = 0; a < AP; ++a) waj[jj][a] = Wa[j * A + (a < A ? a : 0)];
     }
     float dl[NV];
-    load_row_and_grad<AP>(probs, values, actions, y, adv, i, A, beta, s, dl, nullptr);   // every thread: same row
+    load_row_and_grad<AP>(probs, values, actions, y, adv, i, A, beta, s, dl, nullptr, rt);   // every thread: same row
 #pragma unroll
     for (int jj = 0; jj < JPT; ++jj) {
       const int j = tid + jj * 256;
@@ -322,7 +370,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
       __syncthreads();
       if (tid < cnt) {
         float dl[NV];
-        load_row_and_grad<AP>(probs, values, actions, y, adv, i0 + tid, A, beta, s, dl, nullptr);
+        load_row_and_grad<AP>(probs, values, actions, y, adv, i0 + tid, A, beta, s, dl, nullptr, rt);
 #pragma unroll
         for (int a = 0; a < NV; ++a) smem[tid * NV + a] = dl[a];
       }
@@ -360,10 +408,25 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
   for (int a = 0; a < NS; ++a) accv[a] = 0.f;
   for (int i = tid; i < B; i += 256) {
     float dl[NV], stats[3];
-    load_row_and_grad<AP>(probs, values, actions, y, adv, i, A, beta, s, dl, stats);
+    float yv, av;
+    load_row_and_grad<AP>(probs, values, actions, y, adv, i, A, beta, s, dl, stats, rt, &yv, &av);
+    if (rt.v_boot) {          // the learner's records of the returns (paac.py:151-154 feed layout)
+      rt.y_out[i] = yv;
+      rt.adv_out[i] = av;
+    }
 #pragma unroll
     for (int a = 0; a < NV; ++a) accv[a] += dl[a];
     accv[NV] += stats[0]; accv[NV + 1] += stats[1]; accv[NV + 2] += stats[2];
+  }
+  if (rt.v_boot && tid == 0) {      // per-cycle bookkeeping (paac.py:127, actor_learner.py:119-123)
+    if (rt.global_step) {
+      const int64_t step = *rt.global_step + rt.step_inc;
+      *rt.global_step = step;
+      double lr = 0.0;
+      if (step <= rt.anneal) lr = rt.lr0 - ((double)step * rt.lr0 / (double)rt.anneal);
+      *rt.lr_out = (float)lr;
+    }
+    if (rt.tick) *rt.tick += rt.tick_inc;
   }
   block_sums_256<NS>(accv, smem, red);
   if (tid < A) gba[tid] = red[tid];

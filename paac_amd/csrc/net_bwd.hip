@@ -182,7 +182,7 @@ int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s) {
 template <class NT>
 static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
                          const float* y, const float* adv, int batch, float beta, float* grad, float* loss_out,
-                         int phase, hipStream_t s) {
+                         int phase, const ReturnsArgs& rt, hipStream_t s) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[1];
   const int cls = batch_class(batch);
@@ -202,7 +202,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
     launch_heads_bwd<NT::H>(A, dim3(batch + NT::H / 32 + 1), s, (const float*)W.probs, (const float*)W.values, actions, y,
                             adv, (const float*)W.h, wa, wc, A, batch, beta, ctx->dh, grad + L.offset[i_wa],
-                            grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out);
+                            grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out, rt);
   }
   const float* xf = (NT::NCONV == 3) ? W.act[2] : W.act[1];   // flattened last conv output
   float* dxf = (NT::NCONV == 3) ? ctx->dact[2] : ctx->dact[1];
@@ -309,10 +309,19 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
 }
 
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
-                    const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s) {
+                    const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s,
+                    const paac_returns* ret) {
+  ReturnsArgs rt;
+  memset(&rt, 0, sizeof(rt));
+  if (ret) {
+    rt.v_boot = ret->v_boot; rt.rewards = ret->rewards; rt.masks = ret->masks; rt.values_act = ret->values;
+    rt.T = ret->T; rt.N = ret->N; rt.gamma = ret->gamma; rt.y_out = ret->y_out; rt.adv_out = ret->adv_out;
+    rt.global_step = ret->global_step_dev; rt.step_inc = ret->increment; rt.lr0 = ret->initial_lr;
+    rt.anneal = ret->lr_annealing_steps; rt.lr_out = ret->lr_out_dev; rt.tick = ret->tick_dev; rt.tick_inc = ret->tick_inc;
+  }
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return backward_impl<NatureNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, s);
-  return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, s);
+    return backward_impl<NatureNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, rt, s);
+  return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, rt, s);
 }
 
 int64_t wslab_floats_needed(int arch) {

@@ -151,6 +151,30 @@ class Context(object):
                                                1 if forward_done else 0, int(phase), _stream()),
                    "paac_loss_backward")
 
+    def loss_backward_returns(self, params, states, actions, v_boot, rewards, masks, values, gamma, y_out, adv_out,
+                              entropy_beta, grad, loss_out=None, forward_done=False, phase=0, global_step_dev=None,
+                              increment=0, initial_lr=0.0, lr_annealing_steps=1, lr_out_dev=None, tick_dev=None, tick_inc=0):
+        """n-step returns (+ the cycle's schedule bookkeeping) inside the backward's first launch
+        (include/paac_hip.h: paac_loss_backward_returns) == nstep_returns_tick followed by loss_backward."""
+        B = self._check_states(states)
+        T, N = rewards.shape
+        if T * N != B:
+            raise ValueError("rollout records are [%d,%d] but the batch has %d rows" % (T, N, B))
+        ret = _lib.Returns(
+            v_boot=_ptr(v_boot, torch.float32, N, "v_boot"), rewards=_ptr(rewards, torch.float32, B, "rewards"),
+            masks=_ptr(masks, torch.float32, B, "masks"), values=_ptr(values, torch.float32, B, "values"), T=T, N=N,
+            gamma=float(gamma), y_out=_ptr(y_out, torch.float32, B, "y_out"), adv_out=_ptr(adv_out, torch.float32, B, "adv_out"),
+            global_step_dev=_ptr(global_step_dev, torch.int64, 1, "global_step", True), increment=int(increment),
+            initial_lr=float(initial_lr), lr_annealing_steps=int(lr_annealing_steps),
+            lr_out_dev=_ptr(lr_out_dev, torch.float32, 1, "lr_out", True),
+            tick_dev=_ptr(tick_dev, torch.int64, 1, "tick", True), tick_inc=int(tick_inc))
+        _lib.check(self.lib.paac_loss_backward_returns(
+            self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+            _ptr(states, torch.uint8, B * 28224, "states"), _ptr(actions, torch.int32, B, "actions"), ctypes.byref(ret), B,
+            float(entropy_beta), _ptr(grad, torch.float32, self.layout["total"], "grad"),
+            _ptr(loss_out, torch.float32, 4, "loss_out", True), 1 if forward_done else 0, int(phase), _stream()),
+            "paac_loss_backward_returns")
+
     def clip_rmsprop(self, params, grad, ms, mom, lr_dev, decay, momentum, eps, clip_norm, clip_mode, grad_scale=1.0,
                      gnorm_out=None):
         n = self.layout["total"]

@@ -138,15 +138,16 @@ class DeviceRollout(object):
         # training forward over the T*N rollout rows with the N bootstrap observations appended (paac.py:140-142)
         L.ctx.train_forward(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4),
                             values=self.values_train)
-        # returns + global_step/lr schedule + frame counter in one launch (paac.py:127,144-156)
-        hip_ops.nstep_returns_tick(self.v_boot, self.rewards, self.masks, self.values, L.gamma, self.y, self.adv,
-                                   self.global_step_dev, self.total_envs * T, L.initial_lr, L.lr_annealing_steps,
-                                   L.lr_dev, self.tick, T)
-        # one process: whole backward here; data parallel: heads + fc only (phase 1), so that the all-reduce of
-        # the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
-        L.ctx.loss_backward(params, self.rollout_states(parity), self.actions.view(-1), self.y, self.adv,
-                            L.entropy_beta, L.grad, L.loss_dev, forward_done=True,
-                            phase=1 if (self.phased and not self.single_exchange) else 0)
+        # n-step returns + global_step/lr schedule + frame counter (paac.py:127,144-156) ride in the backward's first
+        # launch.  One process: whole backward here; data parallel: heads + fc only (phase 1), so that the all-reduce
+        # of the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
+        L.ctx.loss_backward_returns(params, self.rollout_states(parity), self.actions.view(-1), self.v_boot, self.rewards,
+                                    self.masks, self.values, L.gamma, self.y, self.adv, L.entropy_beta, L.grad,
+                                    L.loss_dev, forward_done=True,
+                                    phase=1 if (self.phased and not self.single_exchange) else 0,
+                                    global_step_dev=self.global_step_dev, increment=self.total_envs * T,
+                                    initial_lr=L.initial_lr, lr_annealing_steps=L.lr_annealing_steps, lr_out_dev=L.lr_dev,
+                                    tick_dev=self.tick, tick_inc=T)
 
     def _backward_conv(self, parity):
         L = self.L

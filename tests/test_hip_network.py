@@ -434,3 +434,42 @@ def test_optimizer_step_keeps_packed_weights_current(arch, A):
     torch.cuda.synchronize()
     assert torch.equal(g_after, g_repacked)
     ctx.close()
+
+
+@pytest.mark.parametrize("arch,A,T,N", [("NATURE", 4, 5, 8), ("NIPS", 6, 20, 3)])
+def test_backward_with_fused_returns_equals_separate_calls(arch, A, T, N):
+    """paac_loss_backward_returns == paac_nstep_returns_tick + paac_loss_backward: y, adv, lr, counters and the whole
+    gradient bit for bit (the returns arithmetic inside the heads-gradient launch is the returns kernel's)."""
+    from paac_amd import hip_ops
+    B = T * N
+    params, states, idx, _, _ = make_case(arch, A, B, seed=12)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+    p = upload_params(ctx, params)
+    rs = np.random.RandomState(3)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    s, acts = dev(states), dev(idx)
+    v_boot = dev(rs.randn(N).astype(np.float32))
+    rewards = dev(rs.choice([-1.0, 0.0, 1.0], size=(T, N)).astype(np.float32))
+    masks = dev((rs.rand(T, N) > 0.2).astype(np.float32))
+    values = dev(rs.randn(T, N).astype(np.float32))
+    n = ctx.layout["total"]
+    out = []
+    for fused in (False, True):
+        y, adv = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+        gstep = torch.tensor([1000], dtype=torch.int64, device="cuda")
+        tick = torch.tensor([7], dtype=torch.int64, device="cuda")
+        lr = torch.zeros(1, device="cuda")
+        grad, loss = torch.zeros(n, device="cuda"), torch.zeros(4, device="cuda")
+        if fused:
+            ctx.loss_backward_returns(p, s, acts, v_boot, rewards, masks, values, 0.99, y, adv, 0.02, grad, loss,
+                                      global_step_dev=gstep, increment=B, initial_lr=0.0224, lr_annealing_steps=80000000,
+                                      lr_out_dev=lr, tick_dev=tick, tick_inc=T)
+        else:
+            hip_ops.nstep_returns_tick(v_boot, rewards, masks, values, 0.99, y, adv, gstep, B, 0.0224, 80000000, lr, tick, T)
+            ctx.loss_backward(p, s, acts, y, adv, 0.02, grad, loss)
+        torch.cuda.synchronize()
+        out.append((y, adv, gstep, tick, lr, grad, loss))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert int(out[1][2].item()) == 1000 + B and int(out[1][3].item()) == 7 + T
+    ctx.close()
