@@ -379,6 +379,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
         constexpr int MAXQ = (mt_skip_max(LDSC) / 8 + 31) / 32 + 1;   // walks per thread there (a pair of groups per 32 threads)
         const int NG = (N + G - 1) / G;
         const int c1 = J - 1, cg = G * (J - 1);
+        // (at 32 environments the single-lane chase is the faster one: 5.3 k cycles against 7.5 k, tools/probe_sampler.py)
         const bool two_level = N > 64 && (NG - 1) * cg + 2 <= 32 * MAXQ && NG + cg * (NG * (NG - 1) / 2) <= mt_skip_max(LDSC);
         if (!two_level) {
           // one lane hops through the table: N dependent LDS byte reads
