@@ -150,6 +150,7 @@ __global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p
     const int ct = wave & 1, cls = wave >> 1, py = cls >> 1, px = cls & 1;
     unsigned bb[7];
     int opix[7];                 // output pixel in the 20 x 20 image, -1 = none
+    f32x4 a1[7];                 // forward activations the ReLU mask is read from: requested now, consumed in the epilogue
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int pi = 16 * j + li;
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p
       const int pc = ok ? pi : 0;
       const int u = pc / 10, v = pc - 10 * u;
       bb[j] = (unsigned)((u * G::PW + v) * G::PS + kq * 16);
-      opix[j] = ok ? (2 * u + py) * 20 + 2 * v + px : -1;
+      const int op = (2 * u + py) * 20 + 2 * v + px;
+      opix[j] = ok ? op : -1;
+      a1[j] = *reinterpret_cast<const f32x4*>(p.act1 + ((size_t)b * 400 + op) * 32 + 16 * ct + 4 * kq);
     }
     f32x4 acc[7];
 #pragma unroll
@@ -166,12 +169,10 @@ __global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       if (opix[j] < 0) continue;
-      const size_t at = ((size_t)b * 400 + opix[j]) * 32 + 16 * ct + 4 * kq;
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.act1 + at);
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = a1[e] > 0.f ? acc[j][e] : 0.f;
-      *reinterpret_cast<f32x4*>(p.da1 + at) = v;
+      for (int e = 0; e < 4; ++e) v[e] = a1[j][e] > 0.f ? acc[j][e] : 0.f;
+      *reinterpret_cast<f32x4*>(p.da1 + ((size_t)b * 400 + opix[j]) * 32 + 16 * ct + 4 * kq) = v;
     }
   }
 }
