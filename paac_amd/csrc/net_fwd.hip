@@ -137,9 +137,13 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
 #endif
   // regions per sample: as many as keep the launch within about one round of the 256 CUs
   const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
-  int regions = (4 * batch <= 288) ? 4 : (2 * batch <= 288) ? 2 : 1;
-  if (force == 1 || force == 2 || force == 4) regions = force;
-  if (regions == 4) {
+  // (measured: 8 regions of 4x2 beat 4 of 4x4 only while they fit half the CUs -- every workgroup streams all the weights)
+  int regions = (8 * batch <= 128) ? 8 : (4 * batch <= 288) ? 4 : (2 * batch <= 288) ? 2 : 1;
+  if (force == 1 || force == 2 || force == 4 || force == 8) regions = force;
+  if (regions == 8) {
+    if (keep) launch_tower_variant<TowerGeom<4, 2>, true>(a, s);
+    else launch_tower_variant<TowerGeom<4, 2>, false>(a, s);
+  } else if (regions == 4) {
     if (keep) launch_tower_variant<TowerGeom<4, 4>, true>(a, s);
     else launch_tower_variant<TowerGeom<4, 4>, false>(a, s);
   } else if (regions == 2) {

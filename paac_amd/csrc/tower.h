@@ -20,8 +20,9 @@
 //     of K, whichever divides evenly.
 //   * Regions: with 32 acting rows, one workgroup per sample would light 32 of 256 CUs.  A sample is cut into 2x2
 //     overlapping regions of 4x4 conv3 outputs (origins 0 / 3; conv2 6x6, conv1 14x14, input 60x60 each): 128 workgroups,
-//     about 2x redundant conv1 / conv2 arithmetic, no exchange between workgroups.  Training batches (>= 160 rows) use
-//     one workgroup per sample (and also write the fp32 activations the backward pass reads).
+//     about 2x redundant conv1 / conv2 arithmetic, no exchange between workgroups (up to 16 rows: 2x4 regions of 4x2, the
+//     last column shifted back to end at 7).  Training batches (>= 160 rows) use one workgroup per sample (and also write
+//     the fp32 activations the backward pass reads).
 //   * LDS image strides are padded (conv1 plane 80 B per pixel, conv2 plane 160 B) so that the 16 lanes a ds_read_b128
 //     services together fall on 64 distinct banks for the stride-2 / stride-1 walks of conv2 / conv3.
 #pragma once
@@ -111,7 +112,7 @@ struct TowerGeom {
   static constexpr int R2H = R3H + 2, R2W = R3W + 2;                   // conv2 outputs it needs (3x3, stride 1)
   static constexpr int R1H = 2 * R2H + 2, R1W = 2 * R2W + 2;           // conv1 outputs (4x4, stride 2)
   static constexpr int RIH = 4 * R1H + 4, RIW = 4 * R1W + 4;           // input pixels (8x8, stride 4)
-  static constexpr int NRY = (R3H == 7) ? 1 : 2, NRX = (R3W == 7) ? 1 : 2, NR = NRY * NRX;
+  static constexpr int NRY = (7 + R3H - 1) / R3H, NRX = (7 + R3W - 1) / R3W, NR = NRY * NRX;   // regions per axis: the last one is shifted back to end at 7
   static constexpr int P1 = R1H * R1W, P2 = R2H * R2W, P3 = R3H * R3W;
   static constexpr int PT1 = (P1 + 15) / 16, PT2 = (P2 + 15) / 16, PT3 = (P3 + 15) / 16;   // 16-pixel tiles
   static constexpr int S1 = 80, S2 = 160;                              // bytes per pixel in the conv1 / conv2 LDS planes
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
   const int li = lane & 15, kq = lane >> 4;
   const int b = blockIdx.x / G::NR, reg = blockIdx.x % G::NR;
   const int ry = reg / G::NRX, rx = reg % G::NRX;
-  const int y3a = ry * (7 - G::R3H), x3a = rx * (7 - G::R3W);     // region origin in conv3 / conv2 coordinates
+  const int y3n = ry * G::R3H, x3n = rx * G::R3W;                   // first conv3 row / column this region owns
+  const int y3a = y3n < 7 - G::R3H ? y3n : 7 - G::R3H, x3a = x3n < 7 - G::R3W ? x3n : 7 - G::R3W;   // region origin in conv3 / conv2 coordinates
   const int y1a = 2 * y3a, x1a = 2 * x3a;                          // ... in conv1 coordinates
 
   TOWER_STAMP(0);
@@ -487,8 +489,9 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
       }
     }
     if (!G::KSPLIT3 || half == 0) {
-      // overlapping regions: the second region along an axis starts at 7 - R3 and leaves the shared rows / columns to the first
-      const int dup_y = ry ? 2 * G::R3H - 7 : 0, dup_x = rx ? 2 * G::R3W - 7 : 0;
+      // overlapping regions: the last region along an axis is shifted back to end at 7 and leaves the shared rows / columns
+      // to its neighbour
+      const int dup_y = y3n - y3a, dup_x = x3n - x3a;
 #pragma unroll
       for (int j = 0; j < G::NT3; ++j) {
         if (pix[j] < 0) continue;

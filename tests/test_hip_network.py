@@ -350,7 +350,7 @@ def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
     ctx.close()
 
 
-@pytest.mark.parametrize("regions", [4, 2, 1])
+@pytest.mark.parametrize("regions", [8, 4, 2, 1])
 @pytest.mark.parametrize("B,A", [(5, 4), (33, 6)])
 def test_conv_tower_variants(regions, B, A):
     """csrc/tower.h: the fused conv1->conv2->conv3 launch in each of its region layouts (4 overlapping 4x4 regions, 2

@@ -69,7 +69,7 @@ if __name__ == "__main__":
     batches = [int(x) for x in sys.argv[1:]] or [32, 160]
     for B in batches:
         print("B=%d per-layer :" % B, run(B, False, check=B <= 256), flush=True)
-        for regions in (4, 2, 1):
+        for regions in (8, 4, 2, 1):
             if B * regions > 4096:
                 continue
             print("B=%d tower r=%d :" % (B, regions), run(B, True, regions, check=B <= 256), flush=True)
