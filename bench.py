@@ -151,6 +151,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif os.environ.get("PAAC_DIST_FORCE", "") == "1":
+        # one-GPU rehearsal of the data-parallel cycle: an RCCL group of ONE rank; with PAAC_FORCE_COLLECTIVES=1 the phased
+        # graphs and the stream-ordered all-reduce calls really run (what they cost besides the wire time)
+        from paac_amd import parallel
+        parallel.init_from_env()
+        import torch.distributed as dist
 
     from paac_amd import train
     from paac_amd.paac import DeviceRollout, PAACLearner

@@ -74,9 +74,12 @@ class DeviceRollout(object):
         self.pending_update = False
         # data parallel: the cycle is cut at the gradient exchange (graphs around it, collectives between them)
         self.phased = parallel.collectives_active()
-        # PAAC_ALLREDUCE=single: ONE all-reduce of the whole flat gradient after the full backward (nothing overlapped);
-        # default "split": the fc/heads tail (95 % of the bytes) goes out while the conv backward still computes
-        self.single_exchange = os.environ.get("PAAC_ALLREDUCE", "split") == "single"
+        # default: ONE all-reduce of the whole flat gradient after the full backward, launched on the rollout stream -- one
+        # graph + one collective per cycle (measured with a one-rank RCCL group: +15 us per cycle over the plain replay).
+        # PAAC_ALLREDUCE=split: the fc/heads tail (95 % of the bytes) goes out on the collective's stream while the conv
+        # backward still computes (+61 us per cycle of extra graph launch and cross-stream waits before any wire time: pays
+        # only when the large all-reduce takes longer than about 120 us)
+        self.single_exchange = os.environ.get("PAAC_ALLREDUCE", "single") != "split"
         self.side_group = parallel.side_group() if (self.phased and not self.single_exchange) else None    # collective call
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
@@ -229,21 +232,21 @@ class DeviceRollout(object):
         self.parity ^= 1
 
     def _exchange(self, conv_backward):
-        """Sum all-reduce of the flat gradient in two pieces: the fc/heads tail goes out (on the collective's own
-        stream) while `conv_backward` still computes the conv head on ours; the update waits for both."""
+        """Sum all-reduce of the flat gradient: one collective on our stream after the full backward (conv_backward is
+        None), or in two pieces -- the fc/heads tail goes out on the collective's own stream while `conv_backward` still
+        computes the conv head on ours; the update waits for both."""
         grad = self.L.grad
         if conv_backward is None:          # PAAC_ALLREDUCE=single: the backward is complete, one collective
-            work = parallel.allreduce_sum_async(grad)
-            if work is not None:
-                work.wait()
+            parallel.allreduce_sum_(grad)  # a blocking-style call runs ON our stream: no cross-stream event hops
             return
         tail = parallel.allreduce_sum_async(grad[self.tail_offset:])
         conv_backward()
-        # the small conv part goes out on a second communicator: it does not wait for the 6.4 MB one to finish
-        head = parallel.allreduce_sum_async(grad[:self.tail_offset], group=self.side_group)
-        for work in (tail, head):
-            if work is not None:
-                work.wait()
+        # the small conv part follows the conv backward on our own stream (nothing to overlap it with) and on a second
+        # communicator (it does not queue behind the 6.4 MB one); the update then waits for the large one, which has been
+        # travelling on the collective's stream meanwhile
+        parallel.allreduce_sum_(grad[:self.tail_offset], group=self.side_group)
+        if tail is not None:
+            tail.wait()
 
     def synchronize(self):
         """Completes everything issued so far, including a data-parallel optimizer step still waiting to ride in

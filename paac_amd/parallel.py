@@ -98,10 +98,12 @@ def shard_range(total_envs, r=None, world=None):
     return r * per, (r + 1) * per
 
 
-def allreduce_sum_(flat_grad):
-    """In-place sum all-reduce of the flat gradient (no-op for a single process)."""
+def allreduce_sum_(flat_grad, group=None):
+    """In-place sum all-reduce of the flat gradient (no-op for a single process).  With RCCL a blocking-style call
+    (async_op=False) is launched on the CURRENT stream: it is ordered with the kernels around it like any other launch,
+    without the two cross-stream event waits of an asynchronous collective."""
     if collectives_active():
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return flat_grad
 
 

@@ -21,7 +21,8 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_dir, n_per_rank, cycles):
+def _run(rank, world, port, out_dir, n_per_rank, cycles, mode="single"):
+    os.environ["PAAC_ALLREDUCE"] = mode
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -58,10 +59,12 @@ def _run(rank, world, port, out_dir, n_per_rank, cycles):
         dist.destroy_process_group()
 
 
-def test_two_ranks_track_single_process(tmp_path):
+@pytest.mark.parametrize("mode", ["single", "split"])
+def test_two_ranks_track_single_process(tmp_path, mode):
+    """Both exchange forms: one all-reduce after the full backward (default), and the two-piece one (PAAC_ALLREDUCE=split)."""
     import torch.multiprocessing as mp
     N, cycles = 4, 5
-    mp.spawn(_run, args=(2, _free_port(), str(tmp_path), N, cycles), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, _free_port(), str(tmp_path), N, cycles, mode), nprocs=2, join=True)
     mp.spawn(_run, args=(1, 0, str(tmp_path), 2 * N, cycles), nprocs=1, join=True)
     r0 = np.load(tmp_path / "w2_r0.npz")
     r1 = np.load(tmp_path / "w2_r1.npz")
