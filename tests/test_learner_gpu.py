@@ -139,7 +139,7 @@ def test_device_loop_matches_host_loop(raw_frames, use_graph):
     ("seaquest", 5, 7, 2, "NATURE"),
     ("breakout", 65, 5, 1, "NATURE"),
 ])
-def test_device_loop_matches_oracle(game, N, T, cycles, arch="NATURE"):
+def test_device_loop_matches_oracle(game, N, T, cycles, arch):
     """The device-resident cycle (hipGraph replay, numpy-parity sampler) against the CPU restatement of paac.py:99-165
     on the same synthetic environments and np.random stream: observations and actions bit for bit, values / returns /
     weights within the float tolerance."""
