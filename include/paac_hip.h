@@ -128,7 +128,11 @@ int paac_set_managed_weights(paac_ctx* ctx, int on);
  * on `states` (unless forward_done != 0: paac_train_forward already ran on the same batch), then backward.
  * phase: 0 = everything; 1 = forward (unless done) + heads + fc layer -> the gradients of fc_w .. critic_b, i.e. the
  * contiguous tail [offset(fc_w), total) of the flat buffer (95 % of its bytes); 2 = conv layers -> the head
- * [0, offset(fc_w)).  A data-parallel caller all-reduces the tail while phase 2 still runs.  actions = sampled action index per row (the one-hot's argmax,
+ * [0, offset(fc_w)).  A data-parallel caller all-reduces the tail while phase 2 still runs.  3 = everything, except that
+ * the split-K slabs of the conv weight gradients are summed into `grad` by the NEXT paac_clip_rmsprop on this ctx and
+ * this `grad` (its norm pass does it, in the same order, so norm and update are bit-identical to phase 0; one launch
+ * less): until then the conv part of `grad` is not valid -- for a caller that goes straight to the optimizer step.
+ * actions = sampled action index per row (the one-hot's argmax,
  * paac.py:27), y = critic target, adv = advantage, batch rows t-major (paac.py:151-154).
  * grad: flat, padded layout.  loss_out (nullable, device float[4]) = {loss, actor, critic, mean entropy}. */
 int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
@@ -165,7 +169,8 @@ int paac_loss_backward_returns(paac_ctx* ctx, const float* params, const uint8_t
  *   gn = sqrt(sum g^2); g <- g * clip_norm*min(1/gn, 1/clip_norm)  (mode GLOBAL)
  *   ms += (g^2 - ms)(1-decay); mom = momentum*mom + lr*g/sqrt(ms+eps); var -= mom
  * lr is read from device memory (*lr_dev) so the call can sit in a replayed graph.
- * gnorm_out (nullable): device float receiving gn. */
+ * gnorm_out (nullable): device float receiving gn.  After paac_loss_backward(phase = 3) on the same `grad` the norm pass
+ * first completes the conv part of `grad` (which is therefore written although the parameter is const). */
 int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms, float* mom, int64_t n,
                       const float* lr_dev, float decay, float momentum, float eps, float clip_norm,
                       int clip_mode, float grad_scale, float* gnorm_out, paac_stream_t stream);

@@ -153,8 +153,8 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   PAAC_CHECK_HIP(hipMalloc(&c->dh, (size_t)B * c->spec.fc * sizeof(float)));
   c->wslab_floats = wslab_floats_needed(cfg->arch);
   PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
-  PAAC_CHECK_HIP(hipMalloc(&c->partials, 4096 * sizeof(float)));
-  PAAC_CHECK_HIP(hipMemset(c->partials, 0, 4096 * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->partials, 8192 * sizeof(float)));
+  PAAC_CHECK_HIP(hipMemset(c->partials, 0, 8192 * sizeof(float)));
   {
     const char* v = getenv("PAAC_TOWER");
     c->tower_on = (cfg->arch == PAAC_ARCH_NATURE) && !(v && *v && atoi(v) == 0);
@@ -305,7 +305,7 @@ int paac_loss_backward(paac_ctx* ctx, const float* params, const uint8_t* states
   PAAC_REQUIRE(ctx && params && states && actions && y && adv && grad, "paac_loss_backward: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_loss_backward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
-  PAAC_REQUIRE(phase >= 0 && phase <= 2, "paac_loss_backward: phase %d", phase);
+  PAAC_REQUIRE(phase >= 0 && phase <= 3, "paac_loss_backward: phase %d", phase);
   int rc = 0;
   if (!forward_done && phase != 2) {
     rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, (hipStream_t)stream);
@@ -325,7 +325,7 @@ int paac_loss_backward_returns(paac_ctx* ctx, const float* params, const uint8_t
   PAAC_REQUIRE(ctx && params && states && actions && ret && grad, "paac_loss_backward_returns: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_loss_backward_returns: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
-  PAAC_REQUIRE(phase >= 0 && phase <= 2, "paac_loss_backward_returns: phase %d", phase);
+  PAAC_REQUIRE(phase >= 0 && phase <= 3, "paac_loss_backward_returns: phase %d", phase);
   PAAC_REQUIRE(ret->T > 0 && ret->N > 0 && ret->T * ret->N == batch, "paac_loss_backward_returns: T*N = %d*%d != batch %d",
                ret->T, ret->N, batch);
   PAAC_REQUIRE(ret->v_boot && ret->rewards && ret->masks && ret->values && ret->y_out && ret->adv_out,

@@ -81,6 +81,19 @@ struct Tune {
 };
 inline int batch_class(int batch) { return batch > 512 ? 2 : batch > 64 ? 1 : 0; }
 
+// Split-K slab reduction of the conv weight gradients into the flat gradient (net_bwd.hip): segments of one backward.
+struct FinalizeSeg {
+  const float* src;  // first slab
+  float* dst;
+  int count;         // floats
+  int splits;
+  long stride;       // floats between slabs
+};
+struct FinalizeArgs {
+  FinalizeSeg seg[8];
+  int nseg;
+};
+
 }  // namespace paac
 
 struct paac_ctx {
@@ -95,7 +108,11 @@ struct paac_ctx {
   float* dh;       // [max_batch][H]
   float* wslab;    // wgrad split-K slabs (all layers)
   int64_t wslab_floats;
-  float* partials; // sum-of-squares partials
+  float* partials; // norm / gradient-summary partials of the last paac_clip_rmsprop (5 x kNormPartialsMax floats)
+  // paac_loss_backward(phase = 3) leaves the slab reduction of the conv weight gradients to the next paac_clip_rmsprop on
+  // the same gradient buffer (its norm pass does it): the segments, and the buffer they belong to
+  paac::FinalizeArgs pending_fin;
+  const float* pending_fin_grad;   // nullptr: nothing pending
   int fc_splits_max;
   // conv tower (csrc/tower.h, Nature only): conv weights pre-split into bf16 planes in MFMA operand order
   void* tower_pack;      // kTowerPackVecs x 16 bytes, nullptr when the tower is off

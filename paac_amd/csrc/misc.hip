@@ -749,44 +749,103 @@ __global__ void fill_f32_kernel(float* p, float v, int n) {
 
 // =============================================================================================
 // Global-norm clip + TF RMSProp over the flat parameter buffer (actor_learner.py:31-34,56-59,70).
-constexpr int NORM_BLOCKS = 256;
+constexpr int NORM_BLOCKS = 256;         // tail blocks of norm_kernel
+constexpr int kNormPartialsMax = 1024;   // head blocks + tail blocks; unused slots stay 0 (the optimizer step sums all of them)
+constexpr int NORM_LANES = 8;            // lanes that share one float4 of the head (the slab sums of net_bwd.hip's finalize)
 
-// partials layout (NORM_BLOCKS floats each): [0] sum of squares (what the clip needs), then what the reference's gradient
-// summaries need (logger_utils.py:23-33 over the flat gradient, actor_learner.py:85-87): [1] sum, [2] max and [3] min over
-// the NONZERO elements, [4] number of exact zeros.  The flat buffer's alignment pads are zeros the reference's flat
-// gradient does not contain; the reader (grad_stats_kernel) knows how many pads there are, so zeros count for max / min
-// only when more zeros were seen than there are pads.  A few VALU ops per element on a latency-bound kernel.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float scale,
-                                                    float* __restrict__ partials) {
-  // latency-bound (a few float4 per thread): every load of a pass is issued before the first one is consumed
-  constexpr int U = 8;
-  constexpr long STRIDE = (long)NORM_BLOCKS * 256;
+// The flat gradient is [conv tensors | fc_w fc_b actor critic] (TF variable order).  The norm pass walks it as
+//   head blocks: the conv tensors, 32 float4 per block, NORM_LANES adjacent lanes per float4.  After a backward that left
+//                its slab reduction pending (paac_loss_backward phase 3) the lanes sum the split-K slabs -- lane r takes
+//                slabs r, r + 8, ... (up to 8 loads in flight), then a fixed xor tree -- and lane 0 WRITES the gradient
+//                value before using it; otherwise lane 0 reads the value grad_finalize_kernel wrote with the same
+//                arithmetic.  Either way the same bits enter the same partial: the norm does not depend on the route.
+//   tail blocks: NORM_BLOCKS blocks stride over the rest (fc / heads gradients, written by their kernels).
+// partials layout (kNormPartialsMax floats each): [0] sum of squares (what the clip needs), then what the reference's
+// gradient summaries need (logger_utils.py:23-33 over the flat gradient, actor_learner.py:85-87): [1] sum, [2] max and
+// [3] min over the NONZERO elements, [4] number of exact zeros.  The flat buffer's alignment pads (all in the tail) are
+// zeros the reference's flat gradient does not contain; the reader (grad_stats_kernel) knows how many pads there are, so
+// zeros count for max / min only when more zeros were seen than there are pads.
+struct NormSeg {
+  const float* src;   // first slab (pending reduction) or nullptr
+  long dst4;          // float4 offset of the tensor inside the flat gradient
+  int count4;         // float4s
+  int splits;
+  long stride;        // floats between slabs
+};
+struct NormArgs {
+  NormSeg seg[6];
+  int nseg, head_blocks;
+  long tail_begin4;
+};
+
+__global__ __launch_bounds__(256) void norm_kernel(float* __restrict__ g, long n4, float scale, const NormArgs a,
+                                                   float* __restrict__ partials) {
   float acc = 0.f, sum = 0.f, mx = -INFINITY, mn = INFINITY, zeros = 0.f;
-  const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (long i0 = blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * STRIDE) {
-    float4 v[U];
-    bool live[U];
+  auto take = [&](const float4 q) {
+    const float x = q.x * scale, y = q.y * scale, z = q.z * scale, w = q.w * scale;
+    acc += (x * x + y * y) + (z * z + w * w);
+    sum += (x + y) + (z + w);
+    const float e[4] = {x, y, z, w};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long i = i0 + u * STRIDE;
-      live[u] = i < n4;
-      v[u] = live[u] ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 4; ++c) {
+      const bool nz = e[c] != 0.f;
+      mx = fmaxf(mx, nz ? e[c] : -INFINITY);
+      mn = fminf(mn, nz ? e[c] : INFINITY);
+      zeros += nz ? 0.f : 1.f;
     }
+  };
+  float4* g4 = reinterpret_cast<float4*>(g);
+  if ((int)blockIdx.x < a.head_blocks) {
+    const int r = threadIdx.x % NORM_LANES;
+    long h = (long)blockIdx.x * (256 / NORM_LANES) + threadIdx.x / NORM_LANES;   // float4 inside the concatenated conv tensors
+    NormSeg sg = a.seg[0];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float x = v[u].x * scale, y = v[u].y * scale, z = v[u].z * scale, w = v[u].w * scale;
-      acc += (x * x + y * y) + (z * z + w * w);
-      if (live[u]) {
-        sum += (x + y) + (z + w);
-        const float e[4] = {x, y, z, w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bool nz = e[c] != 0.f;
-          mx = fmaxf(mx, nz ? e[c] : -INFINITY);
-          mn = fminf(mn, nz ? e[c] : INFINITY);
-          zeros += nz ? 0.f : 1.f;
-        }
+    for (int j = 1; j < 6; ++j) {
+      if (j < a.nseg && h >= sg.count4) {
+        h -= sg.count4;
+        sg = a.seg[j];
       }
+    }
+    const bool live = h < sg.count4;     // whole lane groups are live or not: the shuffles below stay inside a group
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (sg.src != nullptr) {
+      for (int s0 = r; s0 < sg.splits; s0 += 8 * NORM_LANES) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int sp = s0 + u * NORM_LANES;
+          t[u] = (live && sp < sg.splits) ? *reinterpret_cast<const f32x4*>(sg.src + (long)sp * sg.stride + 4 * h)
+                                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+      }
+#pragma unroll
+      for (int off = 1; off < NORM_LANES; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], off, 64);
+      }
+      if (live && r == 0) *reinterpret_cast<f32x4*>(g4 + sg.dst4 + h) = v;
+    } else if (live && r == 0) {
+      v = *reinterpret_cast<const f32x4*>(g4 + sg.dst4 + h);
+    }
+    if (live && r == 0) take(make_float4(v[0], v[1], v[2], v[3]));
+  } else {
+    // latency-bound (a few float4 per thread): every load of a pass is issued before the first one is consumed
+    constexpr int U = 8;
+    constexpr long STRIDE = (long)NORM_BLOCKS * 256;
+    for (long i0 = a.tail_begin4 + ((int)blockIdx.x - a.head_blocks) * 256 + threadIdx.x; i0 < n4; i0 += U * STRIDE) {
+      float4 v[U];
+      bool live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = i0 + u * STRIDE;
+        live[u] = i < n4;
+        v[u] = live[u] ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (live[u]) take(v[u]);
     }
   }
 #pragma unroll
@@ -805,20 +864,26 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    partials[NORM_BLOCKS + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    partials[2 * NORM_BLOCKS + blockIdx.x] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-    partials[3 * NORM_BLOCKS + blockIdx.x] = fminf(fminf(red[3][0], red[3][1]), fminf(red[3][2], red[3][3]));
-    partials[4 * NORM_BLOCKS + blockIdx.x] = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+    partials[kNormPartialsMax + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    partials[2 * kNormPartialsMax + blockIdx.x] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    partials[3 * kNormPartialsMax + blockIdx.x] = fminf(fminf(red[3][0], red[3][1]), fminf(red[3][2], red[3][3]));
+    partials[4 * kNormPartialsMax + blockIdx.x] = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
   }
 }
 
-// One workgroup: the partials of the last sumsq_kernel -> out[8] = {sum, sum of squares, max, min, exact zeros among the
-// real (unpadded) elements, 0, 0, 0}.  Launched by the host at the progress-record cadence only.
-__global__ __launch_bounds__(NORM_BLOCKS) void grad_stats_kernel(const float* __restrict__ partials, float pads,
-                                                                 float* __restrict__ out) {
+// One workgroup: the partials of the last norm_kernel (np of them) -> out[8] = {sum, sum of squares, max, min, exact zeros
+// among the real (unpadded) elements, 0, 0, 0}.  Launched by the host at the progress-record cadence only.
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ partials, int np, float pads,
+                                                         float* __restrict__ out) {
   const int t = threadIdx.x;
-  float ss = partials[t], sum = partials[NORM_BLOCKS + t], mx = partials[2 * NORM_BLOCKS + t],
-        mn = partials[3 * NORM_BLOCKS + t], zeros = partials[4 * NORM_BLOCKS + t];
+  float ss = 0.f, sum = 0.f, mx = -INFINITY, mn = INFINITY, zeros = 0.f;
+  for (int i = t; i < np; i += 256) {
+    ss += partials[i];
+    sum += partials[kNormPartialsMax + i];
+    mx = fmaxf(mx, partials[2 * kNormPartialsMax + i]);
+    mn = fminf(mn, partials[3 * kNormPartialsMax + i]);
+    zeros += partials[4 * kNormPartialsMax + i];
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     ss += __shfl_down(ss, off, 64);
@@ -827,16 +892,15 @@ __global__ __launch_bounds__(NORM_BLOCKS) void grad_stats_kernel(const float* __
     mn = fminf(mn, __shfl_down(mn, off, 64));
     zeros += __shfl_down(zeros, off, 64);
   }
-  __shared__ float red[5][NORM_BLOCKS / 64];
+  __shared__ float red[5][4];
   if ((t & 63) == 0) {
     const int w = t >> 6;
     red[0][w] = ss; red[1][w] = sum; red[2][w] = mx; red[3][w] = mn; red[4][w] = zeros;
   }
   __syncthreads();
   if (t == 0) {
-    constexpr int W = NORM_BLOCKS / 64;
     float a = 0.f, b = 0.f, c = -INFINITY, d = INFINITY, z = 0.f;
-    for (int w = 0; w < W; ++w) {
+    for (int w = 0; w < 4; ++w) {
       a += red[0][w]; b += red[1][w]; c = fmaxf(c, red[2][w]); d = fminf(d, red[3][w]); z += red[4][w];
     }
     const float real_zeros = z - pads;
@@ -952,8 +1016,9 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
     v[u] = reinterpret_cast<float4*>(var)[il];
   }
   const float lr = *lr_dev;
-  // every block reduces the same 256 partials in the same order -> identical norm everywhere
-  float acc = partials[tid];
+  // every block reduces the same partials in the same order -> identical norm everywhere (unused slots hold 0)
+  float acc = (partials[tid] + partials[tid + 256]) + (partials[tid + 512] + partials[tid + 768]);
+  static_assert(kNormPartialsMax == 1024, "four partials per thread");
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
@@ -1049,6 +1114,42 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, c
       dst[128] = l;
     }
   }
+}
+
+// The norm pass's view of the flat gradient: the conv tensors (head blocks; with their pending slab reduction when a
+// phase-3 backward left one for `grad`) and where the tail starts.  Returns the number of blocks (= partials), 0 on a
+// mismatch.  grad == nullptr: layout only (paac_grad_stats), nothing is consumed.
+static int fill_norm_args(paac_ctx* ctx, const float* grad, NormArgs* na) {
+  const paac_layout& L = ctx->layout;
+  const int nconv_t = 2 * ctx->spec.nconv;            // conv weights and biases: the first tensors of the layout
+  memset(na, 0, sizeof(*na));
+  const bool pending = grad != nullptr && ctx->pending_fin_grad != nullptr;
+  if (pending && ctx->pending_fin_grad != grad) return 0;
+  long total4 = 0;
+  for (int i = 0; i < nconv_t; ++i) {
+    NormSeg& sg = na->seg[na->nseg++];
+    sg.dst4 = L.offset[i] / 4;
+    sg.count4 = (int)(L.size[i] / 4);
+    if ((L.offset[i] % 4) != 0 || (L.size[i] % 4) != 0) return 0;
+    if (pending) {
+      for (int j = 0; j < ctx->pending_fin.nseg; ++j) {
+        const FinalizeSeg& f = ctx->pending_fin.seg[j];
+        if (f.dst == grad + L.offset[i]) {
+          sg.src = f.src;
+          sg.splits = f.splits;
+          sg.stride = f.stride;
+        }
+      }
+      if (sg.src == nullptr) return 0;
+    }
+    total4 += sg.count4;
+  }
+  na->head_blocks = (int)((total4 + 256 / NORM_LANES - 1) / (256 / NORM_LANES));
+  na->tail_begin4 = L.offset[nconv_t] / 4;
+  if (na->tail_begin4 != total4) return 0;            // the conv tensors are contiguous from 0 (no pads among them)
+  if (na->head_blocks + NORM_BLOCKS > kNormPartialsMax) return 0;
+  if (pending) ctx->pending_fin_grad = nullptr;
+  return na->head_blocks + NORM_BLOCKS;
 }
 
 // The packed copies the optimizer step maintains and the block classes that go with them (from the ctx's layout).
@@ -1317,7 +1418,12 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(ctx, F_CLIP_RMSPROP, (int)(n / 4), s);
   const long n4 = n / 4;
-  launch_k(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), s, PROF_FIRST, grad, n4, grad_scale, ctx->partials);
+  NormArgs na;
+  const int np = fill_norm_args(ctx, grad, &na);
+  PAAC_REQUIRE(np > 0, "paac_clip_rmsprop: a slab reduction is pending for another gradient buffer, or the conv tensors "
+                       "need more than %d norm blocks", kNormPartialsMax - NORM_BLOCKS);
+  launch_k(norm_kernel, dim3((unsigned)np), dim3(256), s, PROF_FIRST, const_cast<float*>(grad), n4, grad_scale, na,
+           ctx->partials);
   PackSpec pk;
   int fc_tiles, conv_tiles;
   long flat4;
@@ -1336,8 +1442,11 @@ int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms
 int paac_grad_stats(paac_ctx* ctx, float* stats_out, paac_stream_t stream) {
   PAAC_REQUIRE(ctx && stats_out, "paac_grad_stats: null argument");
   const float pads = (float)(ctx->layout.total - ctx->layout.total_unpadded);
-  hipLaunchKernelGGL(grad_stats_kernel, dim3(1), dim3(NORM_BLOCKS), 0, (hipStream_t)stream, (const float*)ctx->partials,
-                     pads, stats_out);
+  NormArgs na;
+  const int np = fill_norm_args(ctx, nullptr, &na);
+  PAAC_REQUIRE(np > 0, "paac_grad_stats: no norm layout");
+  hipLaunchKernelGGL(grad_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ctx->partials, np, pads,
+                     stats_out);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -125,17 +125,6 @@ static int launch_wgrad(const GemmArgs& g, int max_split, Tune t, hipStream_t s)
 
 // ---------------------------------------------------------------------------------------------
 // Split-K slab reduction into the flat gradient (deterministic: fixed summation order).
-struct FinalizeSeg {
-  const float* src;  // first slab
-  float* dst;
-  int count;         // floats
-  int splits;
-  long stride;       // floats between slabs
-};
-struct FinalizeArgs {
-  FinalizeSeg seg[8];
-  int nseg;
-};
 // FIN_LANES adjacent lanes share one output float4: lane r sums slabs r, r + FIN_LANES, ... (up to 8 loads, all in
 // flight at once: one memory round trip for up to 64 slabs), then the lanes' partial sums are combined by a fixed
 // xor tree -- the order of the additions never changes from run to run.
@@ -178,7 +167,8 @@ int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s) {
 
 // phase: 0 = whole backward; 1 = heads + fc (gradients of fc_w .. critic_b, the contiguous tail of the flat
 // buffer, 95 % of its bytes); 2 = conv layers (the head of the flat buffer) + slab finalize.  The split lets a
-// data-parallel caller all-reduce the tail while phase 2 still computes.
+// data-parallel caller all-reduce the tail while phase 2 still computes.  3 = whole backward with the slab finalize
+// left to the norm pass of the next paac_clip_rmsprop on `grad` (one launch less; the same sums in the same order).
 template <class NT>
 static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions,
                          const float* y, const float* adv, int batch, float beta, float* grad, float* loss_out,
@@ -196,7 +186,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   const float* w2 = params + L.offset[i_w2];
   const float* w3 = (NT::NCONV == 3) ? params + L.offset[i_w3] : nullptr;
 
-  const bool do_fc = phase == 0 || phase == 1, do_conv = phase == 0 || phase == 2;
+  const bool do_fc = phase == 0 || phase == 1 || phase == 3, do_conv = phase == 0 || phase == 2 || phase == 3;
   // (1) heads: dH, head weight/bias grads, loss scalars
   if (do_fc) {
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
@@ -299,7 +289,11 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
     wgrad_out(i_w1, feats, NT::C1, slab, splits);
   }
-  {
+  ctx->pending_fin_grad = nullptr;
+  if (phase == 3) {
+    ctx->pending_fin = fin;
+    ctx->pending_fin_grad = grad;
+  } else {
     ProfScope ps(ctx, F_GRAD_FINALIZE, batch, s);
     int maxcount = 0;
     for (int i = 0; i < fin.nseg; ++i) maxcount = fin.seg[i].count > maxcount ? fin.seg[i].count : maxcount;

@@ -142,12 +142,14 @@ class DeviceRollout(object):
         L.ctx.train_forward(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4),
                             values=self.values_train)
         # n-step returns + global_step/lr schedule + frame counter (paac.py:127,144-156) ride in the backward's first
-        # launch.  One process: whole backward here; data parallel: heads + fc only (phase 1), so that the all-reduce
-        # of the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
+        # launch.  One process: whole backward here, with the slab reduction of the conv weight gradients left to the norm
+        # pass of the optimizer step that follows (phase 3: one launch less); data parallel: the complete gradient
+        # (phase 0: the all-reduce needs it) or, in the split form, heads + fc only (phase 1), so that the all-reduce of
+        # the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
         L.ctx.loss_backward_returns(params, self.rollout_states(parity), self.actions.view(-1), self.v_boot, self.rewards,
                                     self.masks, self.values, L.gamma, self.y, self.adv, L.entropy_beta, L.grad,
                                     L.loss_dev, forward_done=True,
-                                    phase=1 if (self.phased and not self.single_exchange) else 0,
+                                    phase=(0 if self.single_exchange else 1) if self.phased else 3,
                                     global_step_dev=self.global_step_dev, increment=self.total_envs * T,
                                     initial_lr=L.initial_lr, lr_annealing_steps=L.lr_annealing_steps, lr_out_dev=L.lr_dev,
                                     tick_dev=self.tick, tick_inc=T)

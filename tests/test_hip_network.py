@@ -145,7 +145,7 @@ def test_backward_phases_compose(arch, A, B):
         used[t["offset"]:t["offset"] + t["size"]] = True
     assert torch.equal(split[used], whole[used])
     with pytest.raises(Exception):
-        ctx.loss_backward(p, *dev, 0.02, split, phase=3)
+        ctx.loss_backward(p, *dev, 0.02, split, phase=4)
     ctx.close()
 
 
@@ -433,6 +433,38 @@ def test_optimizer_step_keeps_packed_weights_current(arch, A):
     ctx.loss_backward(p, s, *dev, 0.02, g_repacked)
     torch.cuda.synchronize()
     assert torch.equal(g_after, g_repacked)
+    ctx.close()
+
+
+@pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NIPS", 6, 24), ("NATURE", 18, 40)])
+def test_deferred_slab_reduction_is_bit_identical(arch, A, B):
+    """paac_loss_backward(phase=3) leaves the split-K slab sums of the conv weight gradients to the norm pass of the next
+    paac_clip_rmsprop: norm, updated weights, optimizer slots AND the completed gradient buffer equal the phase-0 route
+    bit for bit; a pending reduction for another buffer is refused."""
+    from paac_amd import hip_ops, _lib
+    params, states, idx, y, adv = make_case(arch, A, B, seed=21)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+    n = ctx.layout["total"]
+    s = torch.from_numpy(states).cuda()
+    dev = [torch.from_numpy(a).cuda() for a in (idx, y, adv)]
+    out = []
+    for phase in (0, 3):
+        p = upload_params(ctx, params)
+        grad = torch.zeros(n, device="cuda")
+        ms, mom, gn = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+        ctx.loss_backward(p, s, *dev, 0.02, grad, phase=phase)
+        if phase == 3:
+            with pytest.raises(RuntimeError):
+                ctx.clip_rmsprop(p, torch.zeros(n, device="cuda"), ms, mom, torch.tensor([0.05], device="cuda"), 0.99, 0.0,
+                                 0.1, 3.0, _lib.CLIP_GLOBAL)
+        ctx.clip_rmsprop(p, grad, ms, mom, torch.tensor([0.05], device="cuda"), 0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL,
+                         gnorm_out=gn)
+        stats = ctx.grad_stats(3.0, _lib.CLIP_GLOBAL)
+        torch.cuda.synchronize()
+        out.append((p.cpu().numpy(), grad.cpu().numpy(), ms.cpu().numpy(), float(gn.item()), stats))
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, b)
+    assert out[0][3] == out[1][3] and out[0][4] == out[1][4]
     ctx.close()
 
 

@@ -88,7 +88,7 @@ for name, pat, b in FUSED:
             fam["conv_tower[batch=%d]" % bb] = traffic["%s|%s" % k]
     elif ks:
         fam["%s[batch=%d]" % (name, b)] = traffic["%s|%s" % ks[-1]]
-rk = [k for k in fe if "rmsprop_kernel" in k[0] or "sumsq_kernel" in k[0]]
+rk = [k for k in fe if "rmsprop_kernel" in k[0] or "sumsq_kernel" in k[0] or "norm_kernel" in k[0]]
 if rk:
     fam["clip_rmsprop[batch=%d]" % 0] = sum(traffic["%s|%s" % k] for k in rk)
 json.dump({"workload": meta["config"]["workload"], "bytes_per_launch": fam,
