@@ -97,6 +97,12 @@ int paac_forward_sample_synth_step(paac_ctx* ctx, const float* params, const uin
  * values: nullable f32[batch]. */
 int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* values,
                        paac_stream_t stream);
+/* The same without the heads (it stops after the fc layer): the next paac_loss_backward[_returns](forward_done=1) on this
+ * ctx finishes them -- inside its first launch when it is a whole backward (phase 0 / 3) of the three-conv network (one
+ * launch less per update; every value bit-identical), as a launch of their own otherwise.  Batches of up to 64 rows run
+ * the whole forward.  With paac_loss_backward_returns and ret->v_boot == NULL the bootstrap values are taken from rows
+ * [batch, batch + N) of this forward (paac.py:140-142: the bootstrap observations appended to the rollout rows). */
+int paac_train_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream);
 
 /* One whole acting step of the device-resident loop in three launches (paac.py:104-127 for N <= 64 environments with
  * the reference's numpy sampler): policy forward on `states` (conv tower, fc with the head contractions in its epilogue),

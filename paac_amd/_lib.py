@@ -53,6 +53,7 @@ _SIGNATURES = {
     "paac_forward_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_void_p, c_uint64,
                                     c_uint32, c_void_p, c_void_p]),
     "paac_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "paac_train_forward_trunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "paac_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "paac_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p]),

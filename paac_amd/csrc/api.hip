@@ -151,6 +151,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
     PAAC_CHECK_HIP(hipMalloc(&c->dact[i], (size_t)B * cs.oh * cs.ow * cs.cout * sizeof(float)));
   }
   PAAC_CHECK_HIP(hipMalloc(&c->dh, (size_t)B * c->spec.fc * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->dl_buf, (size_t)B * paac::kDlStride * sizeof(float)));
   c->wslab_floats = wslab_floats_needed(cfg->arch);
   PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
   PAAC_CHECK_HIP(hipMalloc(&c->partials, 8192 * sizeof(float)));
@@ -189,7 +190,7 @@ int paac_destroy(paac_ctx* c) {
   }
   for (int i = 0; i < 3; ++i)
     if (c->dact[i]) (void)hipFree(c->dact[i]);
-  float* bufs[] = {c->dh, c->wslab, c->partials};
+  float* bufs[] = {c->dh, c->wslab, c->partials, c->dl_buf};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (c->tower_pack) (void)hipFree(c->tower_pack);
@@ -237,6 +238,16 @@ int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_train_forward: batch %d outside (0, max_batch=%d]", batch,
                ctx->max_batch);
   const int rc = launch_forward(ctx, 1, params, states, batch, nullptr, nullptr, values, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paac_train_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states, "paac_train_forward_trunk: null argument");
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch, "paac_train_forward_trunk: batch %d outside (0, max_batch=%d]", batch,
+               ctx->max_batch);
+  const int rc = launch_forward_trunk_train(ctx, params, states, batch, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -328,8 +339,11 @@ int paac_loss_backward_returns(paac_ctx* ctx, const float* params, const uint8_t
   PAAC_REQUIRE(phase >= 0 && phase <= 3, "paac_loss_backward_returns: phase %d", phase);
   PAAC_REQUIRE(ret->T > 0 && ret->N > 0 && ret->T * ret->N == batch, "paac_loss_backward_returns: T*N = %d*%d != batch %d",
                ret->T, ret->N, batch);
-  PAAC_REQUIRE(ret->v_boot && ret->rewards && ret->masks && ret->values && ret->y_out && ret->adv_out,
+  PAAC_REQUIRE(ret->rewards && ret->masks && ret->values && ret->y_out && ret->adv_out,
                "paac_loss_backward_returns: null rollout record");
+  PAAC_REQUIRE(ret->v_boot || (forward_done && batch + ret->N <= ctx->max_batch),
+               "paac_loss_backward_returns: v_boot == NULL takes the bootstrap values from rows [batch, batch + N) of a "
+               "training forward that has already run over batch + N rows");
   PAAC_REQUIRE(!ret->global_step_dev || (ret->lr_out_dev && ret->lr_annealing_steps > 0),
                "paac_loss_backward_returns: schedule bookkeeping needs lr_out_dev and lr_annealing_steps");
   int rc = 0;

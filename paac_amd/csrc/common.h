@@ -81,6 +81,8 @@ struct Tune {
 };
 inline int batch_class(int batch) { return batch > 512 ? 2 : batch > 64 ? 1 : 0; }
 
+constexpr int kDlStride = 36;   // floats per row of paac_ctx::dl_buf (heads.h)
+
 // Split-K slab reduction of the conv weight gradients into the flat gradient (net_bwd.hip): segments of one backward.
 struct FinalizeSeg {
   const float* src;  // first slab
@@ -113,6 +115,10 @@ struct paac_ctx {
   // the same gradient buffer (its norm pass does it): the segments, and the buffer they belong to
   paac::FinalizeArgs pending_fin;
   const float* pending_fin_grad;   // nullptr: nothing pending
+  // paac_train_forward_trunk stopped the training forward (ws[1]) after the fc layer's split-K slabs: rows covered and
+  // slab count; the next backward finishes the heads (fused into its first launch where it can)
+  int heads_pending_rows, heads_pending_splits;
+  float* dl_buf;                   // [max_batch][kDlStride] per-row head gradients + loss terms (heads.h)
   int fc_splits_max;
   // conv tower (csrc/tower.h, Nature only): conv weights pre-split into bf16 planes in MFMA operand order
   void* tower_pack;      // kTowerPackVecs x 16 bytes, nullptr when the tower is off
@@ -172,6 +178,8 @@ inline void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, int part, A
 }
 
 // launchers implemented in the kernel translation units
+int launch_forward_trunk_train(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, hipStream_t s);
+int launch_deferred_heads(paac_ctx* ctx, const float* params, hipStream_t s);
 int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* states, int batch, float* logits,
                    float* probs, float* values, hipStream_t s);
 struct SynthStepArgs;

@@ -72,9 +72,24 @@ struct KoffD2 {   // conv2 data gradient, one parity class: k-step i = (tap i / 
   __device__ static constexpr int at(int i) { return (((i / 2) / 2) * DgGeom::PW + ((i / 2) % 2)) * DgGeom::PS + (i % 2) * 64; }
 };
 
-__global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p) {
+// hg.blocks > 0: workgroups [batch, batch + hg.blocks) are not samples but the row reductions of the head gradients
+// (heads.h: heads_param_grads -- head weight / bias gradients and the loss scalars from the per-row gradients the fused
+// training-heads launch left behind).  They wait on nothing this kernel produces and run on CUs the 160 sample
+// workgroups leave idle: a place to be, not a dependency.
+__global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p, const HeadsGradArgs hg) {
   using G = DgGeom;
   __shared__ __attribute__((aligned(16))) char lds[G::LDS_BYTES];
+  if ((int)blockIdx.x >= p.batch) {
+    if (threadIdx.x >= 256) return;
+    static_assert(G::LDS_BYTES >= (32 + 4) * 264 * 4 + 64 * 4, "head-gradient scratch");
+    float* smem = reinterpret_cast<float*>(lds);
+    const int role = (int)blockIdx.x - p.batch;
+    if (hg.A <= 4) heads_param_grads<512, 4>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
+    else if (hg.A <= 8) heads_param_grads<512, 8>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
+    else if (hg.A <= 20) heads_param_grads<512, 20>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
+    else heads_param_grads<512, 32>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
+    return;
+  }
   char* const lds_d3 = lds;                 // da3, zero-padded by 2: [3 planes][11 x 11][160 B]
   char* const lds_d2 = lds + 3 * G::PLANE;  // da2, zero-padded by 1
   const int tid = threadIdx.x, lane = tid & 63;

@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     s = fmaxf(s + bj[jj], 0.f);
     h_out[(long)i * H + j] = s;
 #pragma unroll
-    for (int a = 0; a < AP; ++a) part[a] += (a < A) ? s * waj[jj][a] : 0.f;
-    part[AP] += s * wcj[jj];
+    for (int a = 0; a < AP; ++a) part[a] = (a < A) ? fmaf(s, waj[jj][a], part[a]) : part[a];
+    part[AP] = fmaf(s, wcj[jj], part[AP]);
   }
   HEADS_STAMP(1);
   __shared__ float scratch[NV * 256 + NV * 8];
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 template <int AP>
 __device__ __forceinline__ void head_grad_row(const float (&pi)[AP], float v, int act, float y, float adv, float beta,
                                               float s, int A, float (&out)[AP + 1], float* stats) {
+#pragma clang fp contract(off)   // inlined into several kernels that must produce the same bits: no context-dependent fma
   const float eps = 1e-30f;
   float g[AP];
   float dot = 0.f, ent = 0.f, logp = 0.f;
@@ -249,7 +250,9 @@ __device__ __forceinline__ void head_grad_row(const float (&pi)[AP], float v, in
 // per-cycle bookkeeping of paac_nstep_returns_tick (global_step, lr, frame counter).  Arithmetic = nstep_returns_kernel's
 // (csrc/misc.hip), operation for operation.
 struct ReturnsArgs {
-  const float* v_boot;      // nullptr: y / adv are read from the arrays passed to the kernel
+  const float* v_boot;      // nullptr: y / adv are read from the arrays passed to the kernel (unless boot_in_fwd)
+  int boot_in_fwd;          // the training forward covered T*N + N rows: bootstrap value of environment e = value head of
+                            // forward row T*N + e (heads_train_kernel computes it itself; heads_bwd_kernel gets v_boot set)
   const float* rewards;     // [T,N] clipped
   const float* masks;       // [T,N]
   const float* values_act;  // [T,N] values of the acting forwards
@@ -266,9 +269,8 @@ struct ReturnsArgs {
   uint64_t tick_inc;
 };
 
-__device__ __forceinline__ void nstep_row(const ReturnsArgs& r, const int i, float& y, float& adv) {
+__device__ __forceinline__ void nstep_row_from(const ReturnsArgs& r, const int i, const float vb, float& y, float& adv) {
   const int t = i / r.N, e = i - t * r.N;
-  const float vb = r.v_boot[e];
   double R = 0.0;
   for (int tt = r.T - 1; tt >= t; --tt) {
     const long k = (long)tt * r.N + e;
@@ -277,6 +279,9 @@ __device__ __forceinline__ void nstep_row(const ReturnsArgs& r, const int i, flo
   }
   y = (float)R;
   adv = (float)__dsub_rn(R, (double)r.values_act[(long)t * r.N + e]);
+}
+__device__ __forceinline__ void nstep_row(const ReturnsArgs& r, const int i, float& y, float& adv) {
+  nstep_row_from(r, i, r.v_boot[i % r.N], y, adv);
 }
 
 template <int AP>
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
       const int j = tid + jj * 256;
       float acc = dl[AP] * wcj[jj];
 #pragma unroll
-      for (int a = 0; a < AP; ++a) acc += dl[a] * waj[jj][a];
+      for (int a = 0; a < AP; ++a) acc = fmaf(dl[a], waj[jj][a], acc);   // explicit: the two kernels with this line must round alike
       dH[(long)i * H + j] = hv[jj] > 0.f ? acc : 0.f;
     }
     HEADS_STAMP(1);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         const int r = ig + 8 * q;
         if (r < cnt) {
 #pragma unroll
-          for (int a = 0; a < NV; ++a) acc[a] += hv[q] * smem[r * NV + a];
+          for (int a = 0; a < NV; ++a) acc[a] = fmaf(hv[q], smem[r * NV + a], acc[a]);
         }
       }
     }
@@ -442,6 +447,227 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
   HEADS_STAMP(4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training update with the heads FORWARD folded into the heads gradient launch (the training forward stopped after the fc
+// layer's split-K slabs: paac_train_forward_trunk).  Row i's workgroup finishes the forward of its own row (slab sums,
+// bias, ReLU, the two head contractions, softmax) with heads_fwd_kernel's arithmetic, and -- when the returns are computed
+// here -- also the value head of its environment's bootstrap row T*N + e (one more 512-long contraction: cheaper than a
+// launch in between), then the n-step scan, the head gradient of the row and dH, like role 1 of heads_bwd_kernel.  It leaves
+// dl[row][AP + 1] and the three loss terms per row behind; the reductions over rows (head weight / bias gradients, loss
+// scalars: roles 2 and 3) need every row and ride as extra workgroups of a later launch (heads_param_grads, called from
+// dgrad_tower_kernel).  One launch less per update; every value bit-identical to the separate launches.
+static_assert(kDlStride == MAXA + 1 + 3, "floats per row in the dl buffer: AP + 1 gradients (padded to 33) + 3 loss terms");
+
+template <int H, int AP>
+__global__ __launch_bounds__(256) void heads_train_kernel(const float* __restrict__ slab, int splits, long slab_stride,
+                                                          const float* __restrict__ fc_b, const float* __restrict__ Wa,
+                                                          const float* __restrict__ ba, const float* __restrict__ Wc,
+                                                          const float* __restrict__ bc, int A, int B,
+                                                          float* __restrict__ h_out, float* __restrict__ logits_ws,
+                                                          float* __restrict__ probs_ws, float* __restrict__ values_ws,
+                                                          const int32_t* __restrict__ actions, const float* __restrict__ y,
+                                                          const float* __restrict__ adv, float beta, float* __restrict__ dH,
+                                                          float* __restrict__ dl_buf, const ReturnsArgs rt) {
+  constexpr int JPT = H / 256;
+  constexpr int NV = AP + 1;                 // A logits (padded) + value
+  constexpr int NB = NV + 1;                 // + the bootstrap row's value
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x;
+  const bool boot = rt.boot_in_fwd != 0;
+  const int ib = boot ? B + i % rt.N : i;    // forward row holding this environment's bootstrap observation
+  // ---- every independent load first ---------------------------------------------------------------
+  const float head_bias = (tid < A) ? ba[tid] : ((tid == AP || tid == NV) ? bc[0] : 0.f);
+  float sv[JPT][FC_SPLITS_MAX], sb[JPT][FC_SPLITS_MAX], bj[JPT], wcj[JPT], waj[JPT][AP];
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int j = tid + jj * 256;
+#pragma unroll
+    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) {
+      sv[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)i * H + j];
+      sb[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)ib * H + j];
+    }
+    bj[jj] = fc_b[j];
+    wcj[jj] = Wc[j];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) waj[jj][a] = Wa[j * A + (a < A ? a : 0)];
+  }
+  const int act = actions[i];
+  float part[NB], hv[JPT];
+#pragma unroll
+  for (int a = 0; a < NB; ++a) part[a] = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int j = tid + jj * 256;
+    float s = 0.f, sbt = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) {
+      s += (sp < splits) ? sv[jj][sp] : 0.f;
+      sbt += (sp < splits) ? sb[jj][sp] : 0.f;
+    }
+    s = fmaxf(s + bj[jj], 0.f);
+    sbt = fmaxf(sbt + bj[jj], 0.f);
+    hv[jj] = s;
+    h_out[(long)i * H + j] = s;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) part[a] = (a < A) ? fmaf(s, waj[jj][a], part[a]) : part[a];
+    part[AP] = fmaf(s, wcj[jj], part[AP]);
+    part[NV] = fmaf(sbt, wcj[jj], part[NV]);
+  }
+  __shared__ float scratch[NB * 256 + NB * 8];
+  __shared__ float lg[NB];
+  __shared__ float row_s[AP + 3];            // probabilities, then y, adv
+  block_sums_256<NB>(part, scratch, lg);
+  if (tid < NB) lg[tid] += head_bias;
+  __syncthreads();
+  if (tid == 0) {
+    float m = lg[0];
+#pragma unroll
+    for (int a = 1; a < AP; ++a) m = (a < A) ? fmaxf(m, lg[a]) : m;
+    float e[AP];
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      e[a] = (a < A) ? expf(lg[a] - m) : 0.f;
+      sum += e[a];
+    }
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      const float pa = (a < A) ? e[a] / sum : 0.f;
+      row_s[a] = pa;
+      if (a < A) {
+        probs_ws[(long)i * A + a] = pa;
+        logits_ws[(long)i * A + a] = lg[a];
+      }
+    }
+    values_ws[i] = lg[AP];
+    float yv, av;
+    if (rt.rewards) {
+      nstep_row_from(rt, i, boot ? lg[NV] : rt.v_boot[i % rt.N], yv, av);
+      rt.y_out[i] = yv;                      // the learner's records of the returns (paac.py:151-154 feed layout)
+      rt.adv_out[i] = av;
+      if (boot && i < rt.N) values_ws[B + i] = lg[NV];
+    } else {
+      yv = y[i];
+      av = adv[i];
+    }
+    row_s[AP] = yv;
+    row_s[AP + 1] = av;
+    if (i == 0 && rt.rewards) {              // per-cycle bookkeeping (paac.py:127, actor_learner.py:119-123)
+      if (rt.global_step) {
+        const int64_t step = *rt.global_step + rt.step_inc;
+        *rt.global_step = step;
+        double lr = 0.0;
+        if (step <= rt.anneal) lr = rt.lr0 - ((double)step * rt.lr0 / (double)rt.anneal);
+        *rt.lr_out = (float)lr;
+      }
+      if (rt.tick) *rt.tick += rt.tick_inc;
+    }
+  }
+  __syncthreads();
+  float pi[AP], dl[NV], stats[3];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) pi[a] = row_s[a];
+  head_grad_row<AP>(pi, lg[AP], act, row_s[AP], row_s[AP + 1], beta, 5.0f / (float)B, A, dl, stats);   // every thread: same row
+  if (tid == 0) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) dl_buf[(long)i * kDlStride + a] = dl[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dl_buf[(long)i * kDlStride + MAXA + 1 + k] = stats[k];
+  }
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int j = tid + jj * 256;
+    float acc = dl[AP] * wcj[jj];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) acc = fmaf(dl[a], waj[jj][a], acc);   // explicit: the two kernels with this line must round alike
+    dH[(long)i * H + j] = hv[jj] > 0.f ? acc : 0.f;
+  }
+}
+
+// Roles 2 and 3 of heads_bwd_kernel with the per-row head gradients read from dl_buf (written by heads_train_kernel in an
+// earlier launch): role in [0, H/32) = head weight gradients of 32 fc columns; role == H/32 = head bias gradients + loss
+// scalars.  256 threads; smem: at least max((AP + 4) * 264, HB_CHUNK * (AP + 1)) floats.  Same summation orders as there.
+template <int H, int AP>
+__device__ __forceinline__ void heads_param_grads(const int role, const float* __restrict__ h,
+                                                  const float* __restrict__ dl_buf, const int A, const int B,
+                                                  float* __restrict__ gWa, float* __restrict__ gba, float* __restrict__ gWc,
+                                                  float* __restrict__ gbc, float* __restrict__ loss_out, float* smem) {
+  constexpr int NV = AP + 1;
+  constexpr int NS = NV + 3;
+  const int tid = threadIdx.x;
+  if (role < H / 32) {
+    const int jj = tid & 31, ig = tid >> 5;
+    const int j = role * 32 + jj;
+    float acc[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) acc[a] = 0.f;
+    for (int i0 = 0; i0 < B; i0 += HB_CHUNK) {
+      const int cnt = min(HB_CHUNK, B - i0);
+      float hv[HB_CHUNK / 8];
+#pragma unroll
+      for (int q = 0; q < HB_CHUNK / 8; ++q) {       // issue the whole batch of h loads first
+        const int r = ig + 8 * q;
+        hv[q] = h[(long)(i0 + (r < cnt ? r : 0)) * H + j];
+      }
+      __syncthreads();
+      if (tid < cnt) {
+#pragma unroll
+        for (int a = 0; a < NV; ++a) smem[tid * NV + a] = dl_buf[(long)(i0 + tid) * kDlStride + a];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < HB_CHUNK / 8; ++q) {
+        const int r = ig + 8 * q;
+        if (r < cnt) {
+#pragma unroll
+          for (int a = 0; a < NV; ++a) acc[a] = fmaf(hv[q], smem[r * NV + a], acc[a]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NV; ++a) smem[(ig * 32 + jj) * NV + a] = acc[a];
+    __syncthreads();
+    for (int u = tid; u < 32 * NV; u += 256) {
+      const int c = u / NV, a = u - c * NV;
+      float v = 0.f;
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) v += smem[(g8 * 32 + c) * NV + a];
+      const int jo = role * 32 + c;
+      if (a == AP) gWc[jo] = v;
+      else if (a < A) gWa[jo * A + a] = v;
+    }
+    return;
+  }
+  float accv[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) accv[a] = 0.f;
+  for (int i = tid; i < B; i += 256) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) accv[a] += dl_buf[(long)i * kDlStride + a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) accv[NV + k] += dl_buf[(long)i * kDlStride + MAXA + 1 + k];
+  }
+  float* red = smem + NS * 256 + NS * 8;
+  block_sums_256<NS>(accv, smem, red);
+  if (tid < A) gba[tid] = red[tid];
+  if (tid == AP) gbc[0] = red[AP];
+  if (tid == 0 && loss_out) {
+    const float actor = red[NV] / (float)B;
+    const float critic = red[NV + 1] / (float)B;
+    loss_out[0] = 5.0f * (actor + critic);
+    loss_out[1] = actor;
+    loss_out[2] = critic;
+    loss_out[3] = red[NV + 2] / (float)B;
+  }
+}
+struct HeadsGradArgs {        // extra workgroups of dgrad_tower_kernel; blocks == 0: none
+  const float* h;
+  const float* dl_buf;
+  float *gWa, *gba, *gWc, *gbc, *loss_out;
+  int A, B, blocks;
+};
+
 // Dispatch on the action-count bucket.
 template <int H, class... Args>
 inline void launch_heads_fwd(int A, dim3 grid, hipStream_t s, Args... args) {
@@ -449,6 +675,13 @@ inline void launch_heads_fwd(int A, dim3 grid, hipStream_t s, Args... args) {
   else if (A <= 8) launch_k(heads_fwd_kernel<H, 8>, grid, dim3(256), s, PROF_WHOLE, args...);
   else if (A <= 20) launch_k(heads_fwd_kernel<H, 20>, grid, dim3(256), s, PROF_WHOLE, args...);
   else launch_k(heads_fwd_kernel<H, 32>, grid, dim3(256), s, PROF_WHOLE, args...);
+}
+template <int H, class... Args>
+inline void launch_heads_train(int A, dim3 grid, hipStream_t s, Args... args) {
+  if (A <= 4) launch_k(heads_train_kernel<H, 4>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else if (A <= 8) launch_k(heads_train_kernel<H, 8>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else if (A <= 20) launch_k(heads_train_kernel<H, 20>, grid, dim3(256), s, PROF_WHOLE, args...);
+  else launch_k(heads_train_kernel<H, 32>, grid, dim3(256), s, PROF_WHOLE, args...);
 }
 template <int H, class... Args>
 inline void launch_heads_bwd(int A, dim3 grid, hipStream_t s, Args... args) {

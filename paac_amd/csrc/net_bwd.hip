@@ -187,12 +187,37 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   const float* w3 = (NT::NCONV == 3) ? params + L.offset[i_w3] : nullptr;
 
   const bool do_fc = phase == 0 || phase == 1 || phase == 3, do_conv = phase == 0 || phase == 2 || phase == 3;
+  // A trunk-only training forward is waiting for its heads: the whole backward of the three-conv network finishes them
+  // inside the heads-gradient launch (heads_train_kernel; the reductions over rows ride in the dgrad tower launch);
+  // every other route runs the heads launch that was left out first.
+  bool fused_heads = false;
+  if (ctx->heads_pending_rows > 0) {
+    const bool boot_ok = !rt.boot_in_fwd || ctx->heads_pending_rows >= batch + rt.N;
+    if (NT::NCONV == 3 && ctx->tower_on && (phase == 0 || phase == 3) && ctx->heads_pending_rows >= batch && boot_ok) {
+      fused_heads = true;
+    } else {
+      const int rc = launch_deferred_heads(ctx, params, s);
+      if (rc) return rc;
+    }
+  }
+  ReturnsArgs rtl = rt;
+  if (rtl.boot_in_fwd && !fused_heads) {       // the separate heads launch has produced the bootstrap rows' values
+    rtl.v_boot = W.values + batch;
+    rtl.boot_in_fwd = 0;
+  }
   // (1) heads: dH, head weight/bias grads, loss scalars
-  if (do_fc) {
+  if (do_fc && fused_heads) {
+    ProfScope ps(ctx, F_HEADS_BWD, batch, s);
+    const int rows = ctx->heads_pending_rows;
+    launch_heads_train<NT::H>(A, dim3(batch), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * NT::H,
+                              params + L.offset[i_wf + 1], wa, params + L.offset[i_wa + 1], wc, params + L.offset[i_wc + 1], A,
+                              batch, W.h, W.logits, W.probs, W.values, actions, y, adv, beta, ctx->dh, ctx->dl_buf, rtl);
+    ctx->heads_pending_rows = 0;
+  } else if (do_fc) {
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
     launch_heads_bwd<NT::H>(A, dim3(batch + NT::H / 32 + 1), s, (const float*)W.probs, (const float*)W.values, actions, y,
                             adv, (const float*)W.h, wa, wc, A, batch, beta, ctx->dh, grad + L.offset[i_wa],
-                            grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out, rt);
+                            grad + L.offset[i_wa + 1], grad + L.offset[i_wc], grad + L.offset[i_wc + 1], loss_out, rtl);
   }
   const float* xf = (NT::NCONV == 3) ? W.act[2] : W.act[1];   // flattened last conv output
   float* dxf = (NT::NCONV == 3) ? ctx->dact[2] : ctx->dact[1];
@@ -249,7 +274,21 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       da.da2 = ctx->dact[1];
       da.da1 = ctx->dact[0];
       da.batch = batch;
-      launch_k(dgrad_tower_kernel, dim3((unsigned)batch), dim3(512), s, PROF_WHOLE, da);
+      HeadsGradArgs hg;
+      memset(&hg, 0, sizeof(hg));
+      if (fused_heads) {
+        hg.h = W.h;
+        hg.dl_buf = ctx->dl_buf;
+        hg.gWa = grad + L.offset[i_wa];
+        hg.gba = grad + L.offset[i_wa + 1];
+        hg.gWc = grad + L.offset[i_wc];
+        hg.gbc = grad + L.offset[i_wc + 1];
+        hg.loss_out = loss_out;
+        hg.A = A;
+        hg.B = batch;
+        hg.blocks = NT::H / 32 + 1;
+      }
+      launch_k(dgrad_tower_kernel, dim3((unsigned)(batch + hg.blocks)), dim3(512), s, PROF_WHOLE, da, hg);
     } else {
       ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
       launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(gd, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
@@ -308,7 +347,7 @@ int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, c
   ReturnsArgs rt;
   memset(&rt, 0, sizeof(rt));
   if (ret) {
-    rt.v_boot = ret->v_boot; rt.rewards = ret->rewards; rt.masks = ret->masks; rt.values_act = ret->values;
+    rt.v_boot = ret->v_boot; rt.boot_in_fwd = ret->v_boot ? 0 : 1; rt.rewards = ret->rewards; rt.masks = ret->masks; rt.values_act = ret->values;
     rt.T = ret->T; rt.N = ret->N; rt.gamma = ret->gamma; rt.y_out = ret->y_out; rt.adv_out = ret->adv_out;
     rt.global_step = ret->global_step_dev; rt.step_inc = ret->increment; rt.lr0 = ret->initial_lr;
     rt.anneal = ret->lr_annealing_steps; rt.lr_out = ret->lr_out_dev; rt.tick = ret->tick_dev; rt.tick_inc = ret->tick_inc;

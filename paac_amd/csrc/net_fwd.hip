@@ -158,7 +158,7 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
 template <class NT>
 static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
                         float* probs, float* values, const PhiloxArgs& ph, const SynthStepArgs& st, hipStream_t s,
-                        bool defer_heads = false) {
+                        bool defer_heads = false, bool trunk_only = false) {
   const paac_layout& L = ctx->layout;
   Workspace& W = ctx->ws[wsi];
   ctx->last_ws = wsi;
@@ -217,6 +217,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   // Small acting / evaluation batches: fc with the head contractions folded into its epilogue (fc_heads.h), then the
   // head finish -- as its own one-workgroup launch here, or (defer_heads) inside the caller's sampler launch.
   if (small_tail) {
+    if (wsi == 1) ctx->heads_pending_rows = 0;
     constexpr int NTILES = NT::H / 16;
     float* partial = W.fc_slab;      // [NTILES][batch][A + 1]: fits the split-K slab buffer
     const bool keep_h = keep_acts;
@@ -249,6 +250,12 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     g.slab_rows = batch;
     splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
   }
+  if (wsi == 1) ctx->heads_pending_rows = 0;
+  if (trunk_only && wsi == 1) {      // the backward's first launch finishes the heads (heads.h: heads_train_kernel)
+    ctx->heads_pending_rows = batch;
+    ctx->heads_pending_splits = splits;
+    return 0;
+  }
   {
     ProfScope ps(ctx, F_HEADS_FWD, batch, s);
     SynthStepArgs stl = st;
@@ -269,6 +276,45 @@ int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* st
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
   return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
+}
+
+// Training forward up to the fc layer's split-K slabs (batches above the small-batch tail only; smaller ones run the
+// whole forward): the heads are finished by the backward's first launch, or by launch_deferred_heads.
+int launch_forward_trunk_train(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, hipStream_t s) {
+  PhiloxArgs ph;
+  memset(&ph, 0, sizeof(ph));
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    return forward_impl<NatureNet>(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, false, true);
+  return forward_impl<NipsNet>(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, false, true);
+}
+
+// The heads launch a trunk-only training forward left out (a backward that cannot fuse it runs it first).
+int launch_deferred_heads(paac_ctx* ctx, const float* params, hipStream_t s) {
+  const int rows = ctx->heads_pending_rows;
+  if (rows <= 0) return 0;
+  ctx->heads_pending_rows = 0;
+  const paac_layout& L = ctx->layout;
+  const int nt = L.num_tensors;
+  Workspace& W = ctx->ws[1];
+  PhiloxArgs ph;
+  memset(&ph, 0, sizeof(ph));
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
+  const int A = ctx->cfg.num_actions, H = ctx->spec.fc;
+  const float *bf = params + L.offset[nt - 5], *wa = params + L.offset[nt - 4], *ba = params + L.offset[nt - 3],
+              *wc = params + L.offset[nt - 2], *bc = params + L.offset[nt - 1];
+  ProfScope ps(ctx, F_HEADS_FWD, rows, s);
+  if (H == 512)
+    launch_heads_fwd<512>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa, ba, wc,
+                          bc, A, W.h, W.logits, W.probs, W.values, (float*)nullptr, (float*)nullptr, (float*)nullptr, ph, rows,
+                          st);
+  else
+    launch_heads_fwd<256>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa, ba, wc,
+                          bc, A, W.h, W.logits, W.probs, W.values, (float*)nullptr, (float*)nullptr, (float*)nullptr, ph, rows,
+                          st);
+  return 0;
 }
 
 // Acting trunk up to the per-tile head partials (fc_heads.h); the caller's sampler launch finishes the heads.

@@ -134,6 +134,14 @@ class Context(object):
                                                _ptr(values, torch.float32, B, "values", True), _stream()),
                    "paac_train_forward")
 
+    def train_forward_trunk(self, params, states):
+        """Training forward without the heads: the next loss_backward[_returns](forward_done=True) finishes them, inside
+        its first launch where it can (include/paac_hip.h: paac_train_forward_trunk)."""
+        B = self._check_states(states)
+        _lib.check(self.lib.paac_train_forward_trunk(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                                     _ptr(states, torch.uint8, B * 28224, "states"), B, _stream()),
+                   "paac_train_forward_trunk")
+
     def loss_backward(self, params, states, actions, y, adv, entropy_beta, grad, loss_out=None, forward_done=False,
                       phase=0):
         B = states.shape[0]
@@ -155,13 +163,14 @@ class Context(object):
                               entropy_beta, grad, loss_out=None, forward_done=False, phase=0, global_step_dev=None,
                               increment=0, initial_lr=0.0, lr_annealing_steps=1, lr_out_dev=None, tick_dev=None, tick_inc=0):
         """n-step returns (+ the cycle's schedule bookkeeping) inside the backward's first launch
-        (include/paac_hip.h: paac_loss_backward_returns) == nstep_returns_tick followed by loss_backward."""
+        (include/paac_hip.h: paac_loss_backward_returns) == nstep_returns_tick followed by loss_backward.
+        v_boot=None: the bootstrap values are rows [B, B + N) of the training forward that has already run."""
         B = self._check_states(states)
         T, N = rewards.shape
         if T * N != B:
             raise ValueError("rollout records are [%d,%d] but the batch has %d rows" % (T, N, B))
         ret = _lib.Returns(
-            v_boot=_ptr(v_boot, torch.float32, N, "v_boot"), rewards=_ptr(rewards, torch.float32, B, "rewards"),
+            v_boot=_ptr(v_boot, torch.float32, N, "v_boot", True), rewards=_ptr(rewards, torch.float32, B, "rewards"),
             masks=_ptr(masks, torch.float32, B, "masks"), values=_ptr(values, torch.float32, B, "values"), T=T, N=N,
             gamma=float(gamma), y_out=_ptr(y_out, torch.float32, B, "y_out"), adv_out=_ptr(adv_out, torch.float32, B, "adv_out"),
             global_step_dev=_ptr(global_step_dev, torch.int64, 1, "global_step", True), increment=int(increment),

@@ -44,14 +44,12 @@ class DeviceRollout(object):
         # forward at batch N*(T+1) serves the update and the bootstrap); the last environment step of an odd cycle
         # writes its new stacks to slot 2T AND to slot 0 (stack_out2).  Two captured graphs alternate.
         self.states = torch.zeros((2 * T + 1, N, 84, 84, 4), dtype=torch.uint8, device=dev)
-        self.values_train = torch.zeros(((T + 1) * N,), dtype=torch.float32, device=dev)
         self.parity = 0
         self.actions = torch.zeros((T, N), dtype=torch.int32, device=dev)
         self.values = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.rewards = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.masks = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.probs = torch.zeros((N, A), dtype=torch.float32, device=dev)
-        self.v_boot = self.values_train[T * N:]
         self.y = torch.zeros((T * N,), dtype=torch.float32, device=dev)
         self.adv = torch.zeros((T * N,), dtype=torch.float32, device=dev)
         self.ep_reward = torch.zeros((N,), dtype=torch.float32, device=dev)
@@ -139,14 +137,15 @@ class DeviceRollout(object):
                                self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
                                stack_out2=wrap, raw_scratch=self.raw)
         # training forward over the T*N rollout rows with the N bootstrap observations appended (paac.py:140-142)
-        L.ctx.train_forward(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4),
-                            values=self.values_train)
+        # (the forward stops after the fc layer: the heads of the rollout rows AND the value head of the bootstrap rows are
+        # finished inside the backward's first launch)
+        L.ctx.train_forward_trunk(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4))
         # n-step returns + global_step/lr schedule + frame counter (paac.py:127,144-156) ride in the backward's first
         # launch.  One process: whole backward here, with the slab reduction of the conv weight gradients left to the norm
         # pass of the optimizer step that follows (phase 3: one launch less); data parallel: the complete gradient
         # (phase 0: the all-reduce needs it) or, in the split form, heads + fc only (phase 1), so that the all-reduce of
         # the fc/heads gradient tail overlaps the conv backward (phase 2, _backward_conv)
-        L.ctx.loss_backward_returns(params, self.rollout_states(parity), self.actions.view(-1), self.v_boot, self.rewards,
+        L.ctx.loss_backward_returns(params, self.rollout_states(parity), self.actions.view(-1), None, self.rewards,
                                     self.masks, self.values, L.gamma, self.y, self.adv, L.entropy_beta, L.grad,
                                     L.loss_dev, forward_done=True,
                                     phase=(0 if self.single_exchange else 1) if self.phased else 3,

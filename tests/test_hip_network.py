@@ -468,6 +468,56 @@ def test_deferred_slab_reduction_is_bit_identical(arch, A, B):
     ctx.close()
 
 
+@pytest.mark.parametrize("arch,A,T,N,phase", [("NATURE", 4, 5, 32, 0), ("NATURE", 6, 5, 32, 3), ("NATURE", 18, 20, 4, 0),
+                                              ("NATURE", 4, 5, 8, 0), ("NIPS", 6, 5, 16, 0), ("NATURE", 4, 5, 32, 1)])
+def test_trunk_forward_with_heads_in_the_backward_is_bit_identical(arch, A, T, N, phase):
+    """paac_train_forward_trunk + paac_loss_backward_returns(v_boot=NULL): the heads forward of the rollout rows and the
+    value head of the bootstrap rows ride in the backward's first launch (three-conv network, whole backward), or run as
+    the launch that was left out (other networks / phases / small batches).  Gradient, returns, loss terms, schedule and
+    the update equal paac_train_forward + paac_loss_backward_returns(v_boot=values[B:]) bit for bit."""
+    from paac_amd import hip_ops, _lib
+    B = T * N
+    params, states, idx, _, _ = make_case(arch, A, B + N, seed=31)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B + N)
+    rs = np.random.RandomState(5)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    s, acts = dev(states), dev(idx[:B])
+    rewards = dev(rs.choice([-1.0, 0.0, 1.0], size=(T, N)).astype(np.float32))
+    masks = dev((rs.rand(T, N) > 0.2).astype(np.float32))
+    values = dev(rs.randn(T, N).astype(np.float32))
+    n = ctx.layout["total"]
+    out = []
+    for fused in (False, True):
+        p = upload_params(ctx, params)
+        y, adv = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+        gstep = torch.tensor([1000], dtype=torch.int64, device="cuda")
+        tick = torch.tensor([7], dtype=torch.int64, device="cuda")
+        lr = torch.zeros(1, device="cuda")
+        grad, loss = torch.zeros(n, device="cuda"), torch.zeros(4, device="cuda")
+        kw = dict(global_step_dev=gstep, increment=B, initial_lr=0.0224, lr_annealing_steps=80000000, lr_out_dev=lr,
+                  tick_dev=tick, tick_inc=T, forward_done=True)
+        if fused:
+            ctx.train_forward_trunk(p, s)
+            v_boot = None
+        else:
+            vt = torch.zeros(B + N, device="cuda")
+            ctx.train_forward(p, s, values=vt)
+            v_boot = vt[B:]
+        if phase == 1:
+            ctx.loss_backward_returns(p, s[:B], acts, v_boot, rewards, masks, values, 0.99, y, adv, 0.02, grad, loss, phase=1, **kw)
+            ctx.loss_backward(p, s[:B], acts, y, adv, 0.02, grad, loss, forward_done=True, phase=2)
+        else:
+            ctx.loss_backward_returns(p, s[:B], acts, v_boot, rewards, masks, values, 0.99, y, adv, 0.02, grad, loss, phase=phase, **kw)
+        ms, mom, gn = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+        ctx.clip_rmsprop(p, grad, ms, mom, lr, 0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL, gnorm_out=gn)
+        torch.cuda.synchronize()
+        out.append([t.cpu().numpy() for t in (grad, y, adv, loss, gstep, tick, lr, p, ms, gn)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert np.isfinite(out[0][0]).all() and np.abs(out[0][0]).max() > 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("arch,A,T,N", [("NATURE", 4, 5, 8), ("NIPS", 6, 20, 3)])
 def test_backward_with_fused_returns_equals_separate_calls(arch, A, T, N):
     """paac_loss_backward_returns == paac_nstep_returns_tick + paac_loss_backward: y, adv, lr, counters and the whole
