@@ -728,6 +728,27 @@ inline long prepare_dmm(GemmArgs& a, int zdim, int ksplit_z, int xcd_dim) {
   return blocks;
 }
 
+// Two independent contractions in ONE launch: workgroups [0, first1) run body D0 on g0, the rest body D1 on g1 (first1 is
+// a multiple of 8, so each body's XCD-tied tile map still sees its own index modulo 8).  The launch has the larger
+// body's workgroup size; the smaller body's surplus waves end at once (a barrier only counts live waves) and give their
+// registers back, so a workgroup of each kind can share a CU when their LDS and live registers fit together.
+struct PairArgs {
+  GemmArgs g0, g1;
+  int first1, count0;
+};
+template <class D0, class D1>
+__global__ __launch_bounds__((D0::THREADS > D1::THREADS ? D0::THREADS : D1::THREADS))
+__attribute__((amdgpu_waves_per_eu(3, 3))) void dmm_pair_kernel(const PairArgs p) {
+  constexpr int SMEM = D0::SMEM_BYTES > D1::SMEM_BYTES ? D0::SMEM_BYTES : D1::SMEM_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  const int bid = blockIdx.x;
+  if (bid < p.first1) {
+    if (bid < p.count0 && (int)threadIdx.x < D0::THREADS) D0::run(p.g0, bid, smem);
+  } else {
+    if ((int)threadIdx.x < D1::THREADS) D1::run(p.g1, bid - p.first1, smem);
+  }
+}
+
 template <class D>
 inline void launch_dmm(GemmArgs a, int zdim, int ksplit_z, int xcd_dim, hipStream_t s) {
   const long blocks = prepare_dmm<D>(a, zdim, ksplit_z, xcd_dim);

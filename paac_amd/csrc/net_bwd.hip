@@ -224,6 +224,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   FinalizeArgs fin;
   memset(&fin, 0, sizeof(fin));
   float* slab = ctx->wslab;
+  int conv1_splits_done = 0;      // > 0: conv1's weight gradient already ran, paired with conv2's
   // conv wgrads write split-K slabs (+ bias row) into the workspace; grad_finalize_kernel sums them into the
   // flat gradient in a fixed order (deterministic, unlike float atomics).
   auto wgrad_out = [&](int i_w, int feats, int cout, float* base, int splits) {
@@ -307,8 +308,36 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     for (int par = 0; par < 4; ++par) gd.tap_base[par] = (((par >> 1) + 2) * 4 + (par & 1) + 2) * NT::C1 * NT::C2;
     gd.tap_sh = -8 * NT::C1 * NT::C2;
     gd.tap_sw = -2 * NT::C1 * NT::C2;
-    int splits;
-    {
+    int splits = 0;
+    // The conv2 and conv1 weight gradients wait on the data-gradient tower only, and a workgroup of each fits a CU
+    // together (66.5 + 67.6 KB of LDS; 1 x 128 + 2 x 168 registers per SIMD lane): one launch, conv2's workgroups first.
+    if constexpr (NT::NCONV == 3) {
+      static const bool pair_on = env_int("PAAC_WGRAD_PAIR", 1) != 0;
+      const int f1 = 256;
+      GemmArgs g1 = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * 400 * NT::C1 * 4,
+                              slab + (long)W_SPLITS_MAX * (feats + 1) * NT::C2, nullptr, f1, NT::C1, batch * 400, NT::C1, NT::C1);
+      g1.slab_rows = f1 + 1;
+      int c2, k2, x2, c1, k1, x1;
+      resolve_wgrad<false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], c2, k2, x2);
+      resolve_wgrad<true, NT::C1>(g1, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], c1, k1, x1);
+      if (pair_on && ctx->tower_on && c2 == 0 && c1 == kExactBf16 + 2) {
+        using D2 = WgradBody<typename NT::G2, false, NT::C2, 4, 4, 2>;
+        using D1 = WgradBody<typename NT::G1, true, NT::C1, 4, 8, 2, 1>;
+        PairArgs pa;
+        pa.g0 = gw;
+        pa.g1 = g1;
+        pa.count0 = (int)prepare_dmm<D2>(pa.g0, k2, k2, x2);
+        const int n1 = (int)prepare_dmm<D1>(pa.g1, k1, k1, x1);
+        pa.first1 = (pa.count0 + 7) / 8 * 8;
+        {
+          ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
+          launch_k(dmm_pair_kernel<D2, D1>, dim3((unsigned)(pa.first1 + n1)), dim3(512), s, PROF_WHOLE, pa);
+        }
+        splits = k2;
+        conv1_splits_done = k1;
+      }
+    }
+    if (splits == 0) {
       ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
       splits = launch_wgrad<typename NT::G2, false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], s);
     }
@@ -321,11 +350,14 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   }
   // (8) conv1 wgrad from the u8 frames
   {
-    ProfScope ps(ctx, F_CONV1_WGRAD, batch, s);
     const int feats = 256;
-    GemmArgs g = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * 400 * NT::C1 * 4, slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
-    g.slab_rows = feats + 1;
-    const int splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
+    int splits = conv1_splits_done;
+    if (splits == 0) {
+      ProfScope ps(ctx, F_CONV1_WGRAD, batch, s);
+      GemmArgs g = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * 400 * NT::C1 * 4, slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
+      g.slab_rows = feats + 1;
+      splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
+    }
     wgrad_out(i_w1, feats, NT::C1, slab, splits);
   }
   ctx->pending_fin_grad = nullptr;
