@@ -61,6 +61,7 @@ def family_work(name, batch, arch, A, P, raw=False):
         table["conv3_dgrad"] = conv3 + conv2         # conv3 AND conv2 data gradients in one launch (csrc/dgrad_tower.h)
         if os.environ.get("PAAC_WGRAD_PAIR", "1") != "0" and 64 < batch <= 512:
             table["conv2_wgrad"] = conv2 + conv1     # conv2 AND conv1 weight gradients in one launch (dmm_pair_kernel)
+            table["conv3_wgrad"] = conv3 + fc        # fc AND conv3 weight gradients in one launch
     if name in table:
         return "flop", table[name]
     if name == "clip_rmsprop":      # read g (norm) + read g, ms, var + write ms, mom, var (momentum 0: slot not read)

@@ -729,16 +729,16 @@ inline long prepare_dmm(GemmArgs& a, int zdim, int ksplit_z, int xcd_dim) {
 }
 
 // Two independent contractions in ONE launch: workgroups [0, first1) run body D0 on g0, the rest body D1 on g1 (first1 is
-// a multiple of 8, so each body's XCD-tied tile map still sees its own index modulo 8).  The launch has the larger
-// body's workgroup size; the smaller body's surplus waves end at once (a barrier only counts live waves) and give their
-// registers back, so a workgroup of each kind can share a CU when their LDS and live registers fit together.
+// a multiple of 8, so each body's XCD-tied tile map still sees its own index modulo 8).  Pays only when a workgroup of
+// each kind fits a CU together (LDS and registers) and all of them are resident at once; otherwise the second body waits
+// for the first and the launch takes the sum of the two.  (Bodies of different sizes: the launch has the larger size and
+// the smaller body's surplus waves end at once.)
 struct PairArgs {
   GemmArgs g0, g1;
   int first1, count0;
 };
 template <class D0, class D1>
-__global__ __launch_bounds__((D0::THREADS > D1::THREADS ? D0::THREADS : D1::THREADS))
-__attribute__((amdgpu_waves_per_eu(3, 3))) void dmm_pair_kernel(const PairArgs p) {
+__global__ __launch_bounds__((D0::THREADS > D1::THREADS ? D0::THREADS : D1::THREADS)) void dmm_pair_kernel(const PairArgs p) {
   constexpr int SMEM = D0::SMEM_BYTES > D1::SMEM_BYTES ? D0::SMEM_BYTES : D1::SMEM_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
   const int bid = blockIdx.x;

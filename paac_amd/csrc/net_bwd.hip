@@ -225,6 +225,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   memset(&fin, 0, sizeof(fin));
   float* slab = ctx->wslab;
   int conv1_splits_done = 0;      // > 0: conv1's weight gradient already ran, paired with conv2's
+  bool fc_wgrad_held = false;
+  GemmArgs held_gw;
+  int held_ks = 1, held_xcd = -1;
+  memset(&held_gw, 0, sizeof(held_gw));
   // conv wgrads write split-K slabs (+ bias row) into the workspace; grad_finalize_kernel sums them into the
   // flat gradient in a fixed order (deterministic, unlike float atomics).
   auto wgrad_out = [&](int i_w, int feats, int cout, float* base, int splits) {
@@ -239,7 +243,20 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     GemmArgs gw = make_args(xf, (size_t)batch * NT::FLAT * 4, ctx->dh, (size_t)batch * NT::H * 4, grad + L.offset[i_wf], nullptr, NT::FLAT, NT::H, batch, NT::H, NT::H);
     gw.slab_rows = NT::FLAT + 1;
     GemmArgs gd = make_args(ctx->dh, (size_t)batch * NT::H * 4, wf, (size_t)NT::FLAT * NT::H * 4, dxf, xf, batch, NT::FLAT, NT::H, 0, NT::FLAT);
-    {
+    // Whole backward of the three-conv network: the fc weight gradient is held back to share a launch with conv3's (both
+    // in their 2-wave fp32 configurations: 112 registers, 33 KB of LDS -- four workgroups per CU, so all 448 + 432 of them
+    // are resident at once; each alone would prefer another configuration, the tuning table holds the pair-friendly ones
+    // so that every route runs the same arithmetic)
+    if constexpr (NT::NCONV == 3) {
+      static const bool pair2 = env_int("PAAC_WGRAD_PAIR", 1) != 0;
+      int wcfg, wks, wxcd;
+      resolve_wgrad<false, NT::H>(gw, 1, ctx->tune[OP_FC_WGRAD][cls], wcfg, wks, wxcd);
+      fc_wgrad_held = pair2 && do_conv && ctx->tower_on && wcfg == 1;
+      held_gw = gw;
+      held_ks = wks;
+      held_xcd = wxcd;
+    }
+    if (!fc_wgrad_held) {
       ProfScope ps(ctx, F_FC_WGRAD, batch, s);
       launch_wgrad<typename NT::GFC, false, NT::H>(gw, 1, ctx->tune[OP_FC_WGRAD][cls], s);
     }
@@ -258,7 +275,26 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     gd.tap_sh = -3 * NT::C2 * NT::C3;
     gd.tap_sw = -NT::C2 * NT::C3;
     int splits;
-    {
+    int c3 = -1, k3 = 1, x3 = -1;
+    resolve_wgrad<false, NT::C3>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], c3, k3, x3);
+    if (fc_wgrad_held && c3 != 1) {        // not the pair's configuration: the held-back launch goes out on its own
+      ProfScope ps(ctx, F_FC_WGRAD, batch, s);
+      launch_wgrad<typename NT::GFC, false, NT::H>(held_gw, 1, ctx->tune[OP_FC_WGRAD][cls], s);
+      fc_wgrad_held = false;
+    }
+    if (fc_wgrad_held) {
+      using DF = WgradBody<typename NT::GFC, false, NT::H, 4, 2, 2>;
+      using D3 = WgradBody<typename NT::G3, false, NT::C3, 4, 2, 2>;
+      PairArgs pa;
+      pa.g0 = held_gw;
+      pa.g1 = gw;
+      pa.count0 = (int)prepare_dmm<DF>(pa.g0, held_ks, held_ks, held_xcd);
+      const int n1 = (int)prepare_dmm<D3>(pa.g1, k3, k3, x3);
+      pa.first1 = (pa.count0 + 7) / 8 * 8;
+      ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
+      launch_k(dmm_pair_kernel<DF, D3>, dim3((unsigned)(pa.first1 + n1)), dim3(128), s, PROF_WHOLE, pa);
+      splits = k3;
+    } else {
       ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
       splits = launch_wgrad<typename NT::G3, false, NT::C3>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV3_WGRAD][cls], s);
     }
@@ -310,7 +346,8 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     gd.tap_sw = -2 * NT::C1 * NT::C2;
     int splits = 0;
     // The conv2 and conv1 weight gradients wait on the data-gradient tower only, and a workgroup of each fits a CU
-    // together (66.5 + 67.6 KB of LDS; 1 x 128 + 2 x 168 registers per SIMD lane): one launch, conv2's workgroups first.
+    // together (two 4-wave bodies, 133 registers, 66.5 KB of LDS: 2 per CU = the 256 + 256 workgroups of the pair): one
+    // launch.  conv1 runs its 4-wave configuration here (alone its 8-wave one is faster; in the pair it is not).
     if constexpr (NT::NCONV == 3) {
       static const bool pair_on = env_int("PAAC_WGRAD_PAIR", 1) != 0;
       const int f1 = 256;
@@ -320,9 +357,9 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       int c2, k2, x2, c1, k1, x1;
       resolve_wgrad<false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], c2, k2, x2);
       resolve_wgrad<true, NT::C1>(g1, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], c1, k1, x1);
-      if (pair_on && ctx->tower_on && c2 == 0 && c1 == kExactBf16 + 2) {
+      if (pair_on && ctx->tower_on && c2 == 0 && c1 == kExactBf16 + 0) {
         using D2 = WgradBody<typename NT::G2, false, NT::C2, 4, 4, 2>;
-        using D1 = WgradBody<typename NT::G1, true, NT::C1, 4, 8, 2, 1>;
+        using D1 = WgradBody<typename NT::G1, true, NT::C1, 4, 4, 2, 1>;
         PairArgs pa;
         pa.g0 = gw;
         pa.g1 = g1;
@@ -331,7 +368,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
         pa.first1 = (pa.count0 + 7) / 8 * 8;
         {
           ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
-          launch_k(dmm_pair_kernel<D2, D1>, dim3((unsigned)(pa.first1 + n1)), dim3(512), s, PROF_WHOLE, pa);
+          launch_k(dmm_pair_kernel<D2, D1>, dim3((unsigned)(pa.first1 + n1)), dim3(256), s, PROF_WHOLE, pa);
         }
         splits = k2;
         conv1_splits_done = k1;
@@ -430,13 +467,13 @@ void default_tuning(paac_ctx* c) {
   c->tune[OP_CONV3_FWD][1] = Tune{kSplitBf16 + 12, 0, -1};
   c->tune[OP_FC_FWD][0] = Tune{0, 8, 2};
   c->tune[OP_FC_FWD][1] = Tune{kSplitBf16 + 1, 8, 2};
-  c->tune[OP_FC_WGRAD][1] = Tune{0, 1, 0};
+  c->tune[OP_FC_WGRAD][1] = Tune{1, 1, 0};             // 2-wave body: shares a launch with conv3's (backward_impl)
   c->tune[OP_FC_DGRAD][1] = Tune{kSplitBf16 + 1, 0, -1};
-  c->tune[OP_CONV3_WGRAD][1] = Tune{kSplitBf16 + 1, 48, 2};
+  c->tune[OP_CONV3_WGRAD][1] = Tune{1, 48, 2};           // fp32 2-wave body (alone the split-bf16 one is 1.5 us faster)
   c->tune[OP_CONV3_DGRAD][1] = Tune{kSplitBf16 + 11, 0, -1};
   c->tune[OP_CONV2_WGRAD][1] = Tune{0, 32, 2};
   c->tune[OP_CONV2_DGRAD][1] = Tune{9, 0, -1};
-  c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 2, 64, 2};
+  c->tune[OP_CONV1_WGRAD][1] = Tune{kExactBf16 + 0, 64, 2};   // 4-wave body: shares a launch with conv2's
 }
 }  // namespace paac
 
