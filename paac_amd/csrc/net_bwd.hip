@@ -469,7 +469,8 @@ void default_tuning(paac_ctx* c) {
   c->tune[OP_FC_FWD][1] = Tune{kSplitBf16 + 1, 8, 2};
   c->tune[OP_FC_WGRAD][1] = Tune{1, 1, 0};             // 2-wave body: shares a launch with conv3's (backward_impl)
   c->tune[OP_FC_DGRAD][1] = Tune{kSplitBf16 + 1, 0, -1};
-  c->tune[OP_CONV3_WGRAD][1] = Tune{1, 48, 2};           // fp32 2-wave body (alone the split-bf16 one is 1.5 us faster)
+  c->tune[OP_CONV3_WGRAD][1] = Tune{1, 64, 2};           // fp32 2-wave body (alone the split-bf16 one is 1.5 us faster);
+                                                          // 64 slabs: 576 + 448 workgroups = the 1024 that are resident at once
   c->tune[OP_CONV3_DGRAD][1] = Tune{kSplitBf16 + 11, 0, -1};
   c->tune[OP_CONV2_WGRAD][1] = Tune{0, 32, 2};
   c->tune[OP_CONV2_DGRAD][1] = Tune{9, 0, -1};
