@@ -72,18 +72,19 @@ struct KoffD2 {   // conv2 data gradient, one parity class: k-step i = (tap i / 
   __device__ static constexpr int at(int i) { return (((i / 2) / 2) * DgGeom::PW + ((i / 2) % 2)) * DgGeom::PS + (i % 2) * 64; }
 };
 
-// hg.blocks > 0: workgroups [batch, batch + hg.blocks) are not samples but the row reductions of the head gradients
+// hg.blocks > 0: the FIRST hg.blocks workgroups are not samples but the row reductions of the head gradients
 // (heads.h: heads_param_grads -- head weight / bias gradients and the loss scalars from the per-row gradients the fused
 // training-heads launch left behind).  They wait on nothing this kernel produces and run on CUs the 160 sample
-// workgroups leave idle: a place to be, not a dependency.
+// workgroups leave idle: a place to be, not a dependency.  (First, not last: with more samples than CUs the last
+// workgroups of the grid start when everything else is done, and these are long.)
 __global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p, const HeadsGradArgs hg) {
   using G = DgGeom;
   __shared__ __attribute__((aligned(16))) char lds[G::LDS_BYTES];
-  if ((int)blockIdx.x >= p.batch) {
+  if ((int)blockIdx.x < hg.blocks) {
     if (threadIdx.x >= 256) return;
     static_assert(G::LDS_BYTES >= (32 + 4) * 264 * 4 + 64 * 4, "head-gradient scratch");
     float* smem = reinterpret_cast<float*>(lds);
-    const int role = (int)blockIdx.x - p.batch;
+    const int role = (int)blockIdx.x;
     if (hg.A <= 4) heads_param_grads<512, 4>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
     else if (hg.A <= 8) heads_param_grads<512, 8>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
     else if (hg.A <= 20) heads_param_grads<512, 20>(role, hg.h, hg.dl_buf, hg.A, hg.B, hg.gWa, hg.gba, hg.gWc, hg.gbc, hg.loss_out, smem);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(512) void dgrad_tower_kernel(const DgradTowerArgs p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = (int)blockIdx.x - hg.blocks;
 
   // ---- phase 0: da3 of this sample -> padded bf16 planes; the borders (and all of the da2 image) start as zeros ----------
   WaveGemm<18, 3, 4, 3, G::PLANE, 6, KoffD3> g3;
