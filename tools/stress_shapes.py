@@ -10,7 +10,10 @@ CASES = [("breakout", 1, 1, 2, "NATURE"), ("pong", 3, 2, 2, "NIPS"), ("seaquest"
          ("qbert", 7, 5, 2, "NIPS"), ("breakout", 17, 3, 2, "NATURE"), ("qbert", 33, 5, 2, "NATURE"),
          ("breakout", 64, 5, 1, "NATURE"), ("breakout", 65, 5, 1, "NATURE"), ("seaquest", 60, 4, 1, "NIPS"),
          ("seaquest", 61, 2, 1, "NATURE"), ("pong", 100, 2, 1, "NIPS"), ("breakout", 16, 1, 2, "NIPS"),
-         ("qbert", 2, 20, 1, "NATURE")]
+         ("qbert", 2, 20, 1, "NATURE"),
+         # around the batch classes of the paired weight-gradient launches (65 .. 512 training rows)
+         ("breakout", 13, 5, 1, "NATURE"), ("breakout", 14, 5, 2, "NATURE"), ("qbert", 100, 5, 1, "NATURE"),
+         ("breakout", 103, 5, 1, "NATURE"), ("seaquest", 27, 3, 2, "NATURE")]
 bad = 0
 for c in CASES:
     try:
