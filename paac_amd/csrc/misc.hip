@@ -250,6 +250,73 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
   }
 }
 
+// Small shards (up to 32 environments x up to 7 actions) without a table: four groups of 8 environments; group k can be
+// entered at k 8 (J-1) + 1 stream offsets, and one THREAD per (group, entry offset) walks its group from there, deciding
+// each environment's first hit itself (J draws against the environment's J thresholds, all requested before the first
+// compare) and recording the categories it meets -- 8 dependent LDS round trips, all walks side by side (4 + 48 (J-1) <= 256
+// threads).  Then one lane follows the three group exits and every environment picks the record of the walk that really
+// happened.  pj_buf is overwritten with the thresholds.  Returns the consumed-draw count through *used_s.
+template <int JC>
+__device__ __forceinline__ void mt_group_walks(double* pj_buf, const double* u_buf, unsigned char* inv_s, unsigned short* rec_s,
+                                               int* entry_s, int* used_s, const int N, const int D,
+                                               int32_t* __restrict__ actions, int16_t* act_lds) {
+  constexpr int QG = 8, C1 = JC - 1;
+  const int tid = threadIdx.x;
+  for (int d = tid; d < D; d += 256) {                   // hit(U) == ((U > thr) != inv), as mt_fill_table
+    const double pj = pj_buf[d];
+    const bool inv = !(pj <= 0.5);
+    pj_buf[d] = inv ? 1.0 - (1.0 - pj) : 1.0 - pj;
+    inv_s[d] = inv ? 1 : 0;
+  }
+  __syncthreads();
+  MISC_STAMP(5);
+  unsigned char* act_h = reinterpret_cast<unsigned char*>(rec_s);                // [walk <= 256][8 hops]
+  unsigned short* end_h = rec_s + 1024;                                           // [walk] exit offset
+  auto first_walk = [&](const int k) { return k + QG * C1 * (k * (k - 1) / 2); };   // walks of groups 0..k-1
+  const int g = (tid >= first_walk(3)) ? 3 : (tid >= first_walk(2)) ? 2 : (tid >= first_walk(1)) ? 1 : 0;
+  const int h = tid - first_walk(g);
+  if (g * QG < N && h < g * QG * C1 + 1) {
+    int e = g * QG, o = e + h;
+    for (int hop = 0; hop < QG; ++hop) {
+      if (e < N) {
+        double U[JC], T[JC];
+        int I[JC];
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+          U[j] = u_buf[o + j < D ? o + j : D - 1];
+          T[j] = pj_buf[e * JC + j];
+          I[j] = inv_s[e * JC + j];
+        }
+        int jh = JC;
+#pragma unroll
+        for (int j = JC - 1; j >= 0; --j)
+          if ((U[j] > T[j]) != (I[j] != 0)) jh = j;
+        act_h[tid * QG + hop] = (unsigned char)jh;
+        o += (jh + 1 < JC) ? jh + 1 : JC;
+        ++e;
+      }
+    }
+    end_h[tid] = (unsigned short)o;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int k = 0; k * QG < N; ++k) {
+      const int w = first_walk(k) + o - k * QG;          // the walk of group k that really happens
+      entry_s[k] = w;
+      o = end_h[w];
+    }
+    *used_s = o;
+  }
+  __syncthreads();
+  if (tid < N) {
+    const int k = tid / QG;
+    const int jh = act_h[entry_s[k] * QG + (tid - k * QG)];
+    actions[tid] = jh;                                   // jh == J  <=>  no hit  <=>  action A-1 = J
+    if (act_lds) act_lds[tid] = (int16_t)jh;
+  }
+}
+
 // probs_lds (LDSC > 0 only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
 // stw_pre (with probs_lds): the caller requested the 625 state words (3 per thread, clamped index) before producing them.
 template <int LDSC>
@@ -358,7 +425,23 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   if constexpr (LDSPATH) {
     // env e can only start at offsets e .. e J (every earlier env drew between 1 and J doubles)
     const long tab_entries = (long)N + (long)(J - 1) * N * (N - 1) / 2;
-    if (tab_entries <= mt_tab_max(LDSC) && N <= 256) {
+    bool walked = false;
+    if constexpr (LDSC == 1) {
+      if (!any_zero && N <= 32 && 4 + 48 * (J - 1) <= 256) {
+        static_assert(mt_tab_max(1) >= 1024 && mt_skip_max(1) >= 1024 + 256, "walk scratch");
+        switch (J) {
+#define PAAC_WALK_CASE(JJ) \
+  case JJ: mt_group_walks<JJ>(pj_buf, u_buf, jh_tab, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
+          PAAC_WALK_CASE(1) PAAC_WALK_CASE(2) PAAC_WALK_CASE(3) PAAC_WALK_CASE(4) PAAC_WALK_CASE(5)
+          default: mt_group_walks<6>(pj_buf, u_buf, jh_tab, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
+#undef PAAC_WALK_CASE
+        }
+        __syncthreads();
+        walked = true;
+        chased = true;
+      }
+    }
+    if (!walked && tab_entries <= mt_tab_max(LDSC) && N <= 256) {
       if (!any_zero) {     // set in phase 1, visible since the barrier after phase 3
         // Table fill (mt_fill_table): the category count is dispatched to a compile-time constant, so the fill has
         // no branch per category
@@ -381,53 +464,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
         const int c1 = J - 1, cg = G * (J - 1);
         // (at 32 environments the single-lane chase is the faster one: 5.3 k cycles against 7.5 k, tools/probe_sampler.py)
         const bool two_level = N > 64 && (NG - 1) * cg + 2 <= 32 * MAXQ && NG + cg * (NG * (NG - 1) / 2) <= mt_skip_max(LDSC);
-        // Up to 32 environments x up to 7 actions: four groups of 8 environments; group k can be entered at k 8 (J-1) + 1
-        // stream offsets, and one THREAD per (group, entry offset) walks its group from there, recording the categories
-        // it meets -- 8 dependent table reads, all walks side by side (4 + 48 (J-1) <= 256 threads); then one lane follows
-        // the three group exits and every environment picks the record of the walk that really happened.  (The idea of the
-        // two-level chase below, shaped so that nothing is replayed: 2.6 k cycles against 5.3 k for the single-lane chase
-        // at 32 environments x 4 actions.)
-        const bool quad = LDSC == 1 && N <= 32 && 4 + 48 * (J - 1) <= 256;
-        if (quad) {
-          constexpr int QG = 8;
-          unsigned char* act_h = reinterpret_cast<unsigned char*>(skip_tab);      // [walk <= 256][8 hops]
-          unsigned short* end_h = skip_tab + 1024;                                 // [walk] exit offset
-          static_assert(mt_skip_max(1) >= 1024 + 256, "walk records reuse the skip table's LDS");
-          auto first_walk = [&](const int k) { return k + QG * c1 * (k * (k - 1) / 2); };   // walks of groups 0..k-1
-          const int g = (tid >= first_walk(3)) ? 3 : (tid >= first_walk(2)) ? 2 : (tid >= first_walk(1)) ? 1 : 0;
-          const int h = tid - first_walk(g);
-          if (g * QG < N && h < g * QG * c1 + 1) {
-            int e = g * QG, o = e + h;
-            int base = e + c1 * (e * (e - 1) / 2);       // slot of (e, o) = base + o - e
-            for (int hop = 0; hop < QG; ++hop) {
-              if (e < N) {
-                const int jh = jh_tab[base + o - e];
-                act_h[tid * QG + hop] = (unsigned char)jh;
-                o += (jh + 1 < J) ? jh + 1 : J;
-                base += 1 + c1 * e;
-                ++e;
-              }
-            }
-            end_h[tid] = (unsigned short)o;
-          }
-          __syncthreads();
-          if (tid == 0) {
-            int o = 0;
-            for (int k = 0; k * QG < N; ++k) {
-              const int w = first_walk(k) + o - k * QG;  // the walk of group k that really happens
-              entry_s[k] = w;
-              o = end_h[w];
-            }
-            any_zero = o;                                 // reuse as the consumed-draw count
-          }
-          __syncthreads();
-          if (tid < N) {
-            const int k = tid / QG;
-            const int jh = act_h[entry_s[k] * QG + (tid - k * QG)];
-            actions[tid] = jh;                            // jh == J  <=>  no hit  <=>  action A-1 = J
-            if (act_lds) act_lds[tid] = (int16_t)jh;
-          }
-        } else if (!two_level) {
+        if (!two_level) {
           // one lane hops through the table: N dependent LDS byte reads
           if (tid == 0) {
             int o = 0, base = 0, ej = 0;               // base(e) - e = (J-1) e (e-1)/2, ej = e (J-1)
