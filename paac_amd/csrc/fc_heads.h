@@ -133,6 +133,34 @@ __global__ __launch_bounds__(64 * NW) void fc_heads_kernel(const float* __restri
   }
 }
 
+// Second half of the heads finish: logits of all B rows in lg_s -> softmax, stores.  Ends with a barrier.
+__device__ __forceinline__ void heads_softmax_store(const int B, const int A, const float* lg_s, float* probs_lds,
+                                                    float* __restrict__ logits_out, float* __restrict__ probs_out,
+                                                    float* __restrict__ values_out, float* __restrict__ logits_out2,
+                                                    float* __restrict__ probs_out2, float* __restrict__ values_out2) {
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < B * A; idx += 256) {          // one (row, action) per thread; max and sum recomputed per thread
+    const int row = idx / A, a = idx - row * A;
+    const float* lg = lg_s + row * (A + 1);
+    float m = lg[0];
+    for (int j = 1; j < A; ++j) m = fmaxf(m, lg[j]);
+    float sum = 0.f;
+    for (int j = 0; j < A; ++j) sum += expf(lg[j] - m);
+    const float pa = expf(lg[a] - m) / sum;
+    if (probs_lds) probs_lds[idx] = pa;
+    if (probs_out) probs_out[idx] = pa;
+    if (probs_out2) probs_out2[idx] = pa;
+    if (logits_out) logits_out[idx] = lg[a];
+    if (logits_out2) logits_out2[idx] = lg[a];
+  }
+  for (int row = tid; row < B; row += 256) {
+    const float v = lg_s[row * (A + 1) + A];
+    if (values_out) values_out[row] = v;
+    if (values_out2) values_out2[row] = v;
+  }
+  __syncthreads();
+}
+
 // One workgroup (256 threads): partial[NTILES][B][A+1] -> logits, probabilities, values of all B rows.
 // lg_s: LDS scratch of B * (A + 1) floats; probs_lds (nullable): [B][A] in LDS for a consumer in the same workgroup.
 // Ends with a barrier.
@@ -155,26 +183,29 @@ __device__ __forceinline__ void heads_from_partials(const float* __restrict__ pa
     lg_s[idx] = acc;
   }
   __syncthreads();
-  for (int idx = tid; idx < B * A; idx += 256) {          // one (row, action) per thread; max and sum recomputed per thread
-    const int row = idx / A, a = idx - row * A;
-    const float* lg = lg_s + row * (A + 1);
-    float m = lg[0];
-    for (int j = 1; j < A; ++j) m = fmaxf(m, lg[j]);
-    float sum = 0.f;
-    for (int j = 0; j < A; ++j) sum += expf(lg[j] - m);
-    const float pa = expf(lg[a] - m) / sum;
-    if (probs_lds) probs_lds[idx] = pa;
-    if (probs_out) probs_out[idx] = pa;
-    if (probs_out2) probs_out2[idx] = pa;
-    if (logits_out) logits_out[idx] = lg[a];
-    if (logits_out2) logits_out2[idx] = lg[a];
-  }
-  for (int row = tid; row < B; row += 256) {
-    const float v = lg_s[row * (A + 1) + A];
-    if (values_out) values_out[row] = v;
-    if (values_out2) values_out2[row] = v;
-  }
+  heads_softmax_store(B, A, lg_s, probs_lds, logits_out, probs_out, values_out, logits_out2, probs_out2, values_out2);
+}
+
+// The same in two halves for a caller with something to do while the partial loads travel; B (A + 1) <= 256: one (row,
+// output) per thread.  Same sums in the same order as heads_from_partials.
+__device__ __forceinline__ void heads_partials_issue(const float* __restrict__ partial, const int ntiles, const int n,
+                                                     const int A, const float* __restrict__ ba,
+                                                     const float* __restrict__ bc, float (&v)[32], float& bias) {
+  const int idx = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
+  const int a = idx % (A + 1);
+  bias = (a < A) ? ba[a] : bc[0];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];
+}
+__device__ __forceinline__ void heads_from_issued(const float (&v)[32], const float bias, const int ntiles, const int B,
+                                                  const int A, float* lg_s, float* probs_lds, float* __restrict__ probs_out,
+                                                  float* __restrict__ values_out) {
+  float acc = bias;
+#pragma unroll
+  for (int t = 0; t < 32; ++t) acc += (t < ntiles) ? v[t] : 0.f;
+  if ((int)threadIdx.x < B * (A + 1)) lg_s[threadIdx.x] = acc;
   __syncthreads();
+  heads_softmax_store(B, A, lg_s, probs_lds, nullptr, probs_out, values_out, nullptr, nullptr, nullptr);
 }
 
 static __global__ __launch_bounds__(256) void heads_finish_kernel(const float* __restrict__ partial, int ntiles, int B, int A,

@@ -255,20 +255,13 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
 // each environment's first hit itself (J draws against the environment's J thresholds, all requested before the first
 // compare) and recording the categories it meets -- 8 dependent LDS round trips, all walks side by side (4 + 48 (J-1) <= 256
 // threads).  Then one lane follows the three group exits and every environment picks the record of the walk that really
-// happened.  pj_buf is overwritten with the thresholds.  Returns the consumed-draw count through *used_s.
+// happened.  thr_s / inv_s: the thresholds phase 1 left behind.  Returns the consumed-draw count through *used_s.
 template <int JC>
-__device__ __forceinline__ void mt_group_walks(double* pj_buf, const double* u_buf, unsigned char* inv_s, unsigned short* rec_s,
+__device__ __forceinline__ void mt_group_walks(const double* thr_s, const double* u_buf, const unsigned char* inv_s, unsigned short* rec_s,
                                                int* entry_s, int* used_s, const int N, const int D,
                                                int32_t* __restrict__ actions, int16_t* act_lds) {
   constexpr int QG = 8, C1 = JC - 1;
   const int tid = threadIdx.x;
-  for (int d = tid; d < D; d += 256) {                   // hit(U) == ((U > thr) != inv), as mt_fill_table
-    const double pj = pj_buf[d];
-    const bool inv = !(pj <= 0.5);
-    pj_buf[d] = inv ? 1.0 - (1.0 - pj) : 1.0 - pj;
-    inv_s[d] = inv ? 1 : 0;
-  }
-  __syncthreads();
   MISC_STAMP(5);
   unsigned char* act_h = reinterpret_cast<unsigned char*>(rec_s);                // [walk <= 256][8 hops]
   unsigned short* end_h = rec_s + 1024;                                           // [walk] exit offset
@@ -284,7 +277,7 @@ __device__ __forceinline__ void mt_group_walks(double* pj_buf, const double* u_b
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
           U[j] = u_buf[o + j < D ? o + j : D - 1];
-          T[j] = pj_buf[e * JC + j];
+          T[j] = thr_s[e * JC + j];
           I[j] = inv_s[e * JC + j];
         }
         int jh = JC;
@@ -319,12 +312,20 @@ __device__ __forceinline__ void mt_group_walks(double* pj_buf, const double* u_b
 
 // probs_lds (LDSC > 0 only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
 // stw_pre (with probs_lds): the caller requested the 625 state words (3 per thread, clamped index) before producing them.
-template <int LDSC>
+// probs_hook (with probs_lds): produces the probabilities in probs_lds and ends with a barrier.  It is called AFTER the
+// state blocks and the doubles (which need nothing but the state words) so that whatever the hook waits on -- the loads
+// of the head partials it requested earlier -- travels while those phases compute.
+struct NoProbsHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int LDSC, class HOOK = NoProbsHook>
 __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
                                                double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
                                                int32_t* __restrict__ actions, int16_t* act_lds,
-                                               const float* probs_lds = nullptr, const uint32_t* stw_pre = nullptr) {
+                                               const float* probs_lds = nullptr, const uint32_t* stw_pre = nullptr,
+                                               const HOOK probs_hook = HOOK()) {
+  constexpr bool HOOKED = !__is_same(HOOK, NoProbsHook);
   MISC_STAMP(0);
   constexpr bool LDSPATH = LDSC > 0;
   constexpr int PRW = LDSC == 2 ? 18 : 8;             // probability floats per thread of the one-round-trip load
@@ -373,19 +374,33 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   MISC_STAMP(1);
   const float* pr = LDSPATH ? (probs_lds ? probs_lds : probs_s) : probs;
   const int nblk = (int)((pos + 2u * (uint32_t)D) / 624u) + 1;
+  // the walks of the small shards (mt_group_walks) want thresholds: phase 1 leaves them behind too
+  __shared__ __attribute__((aligned(8))) unsigned char jh_tab[mt_tab_max(LDSC)];
+  const bool walk_ok = LDSC == 1 && N <= 32 && 4 + 48 * (J - 1) <= 256;
+  double* thr_s = reinterpret_cast<double*>(jh_tab);           // [D <= 1024]   (the first-hit table is not built then)
+  unsigned char* inv_s = jh_tab + (LDSC == 1 ? 8192 : 0);      // [D]
+  static_assert(LDSC != 1 || mt_tab_max(1) >= 8192 + 1024, "threshold arrays reuse the table's LDS");
   // phase 1: conditional probabilities p_j / remaining_j, one (env, category) per thread: the running
   // `remaining` is rebuilt with the reference's sequential fp64 subtraction order (cheap), so that only ONE fp64
   // division sits on each thread's critical path instead of J in a row
-  for (int d = tid; d < D; d += 256) {
-    const int e = d / J, j = d - e * J;
-    double remaining = 1.0;
-    for (int i = 0; i < j; ++i)
-      remaining -= (double)(pr[(long)e * A + i] - 5.9604644775390625e-08f);   // float32 arithmetic, paac.py:42
-    const double p = (double)(pr[(long)e * A + j] - 5.9604644775390625e-08f);
-    const double cond = p / remaining;
-    pj_buf[d] = cond;
-    if (LDSPATH && cond == 0.0) any_zero = 1;
-  }
+  auto phase1 = [&]() {
+    for (int d = tid; d < D; d += 256) {
+      const int e = d / J, j = d - e * J;
+      double remaining = 1.0;
+      for (int i = 0; i < j; ++i)
+        remaining -= (double)(pr[(long)e * A + i] - 5.9604644775390625e-08f);   // float32 arithmetic, paac.py:42
+      const double p = (double)(pr[(long)e * A + j] - 5.9604644775390625e-08f);
+      const double cond = p / remaining;
+      pj_buf[d] = cond;
+      if (LDSPATH && cond == 0.0) any_zero = 1;
+      if (walk_ok) {                                     // hit(U) == ((U > thr) != inv), as mt_fill_table
+        const bool inv = !(cond <= 0.5);
+        thr_s[d] = inv ? 1.0 - (1.0 - cond) : 1.0 - cond;
+        inv_s[d] = inv ? 1 : 0;
+      }
+    }
+  };
+  if constexpr (!HOOKED) phase1();
   MISC_STAMP(2);
   // phase 2: successive MT19937 state blocks
   if constexpr (!LDSPATH) {
@@ -413,12 +428,16 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     u_buf[d] = ((double)a * 67108864.0 + (double)b) * 1.1102230246251565404e-16;   // * 2^-53, exact
   }
   __syncthreads();
+  if constexpr (HOOKED) {
+    probs_hook();            // ends with a barrier: the probabilities are in LDS
+    phase1();
+    __syncthreads();
+  }
   MISC_STAMP(4);
   // phase 4a (fast path): when every conditional probability is non-zero the stream offset after env e is
   // o + min(jh+1, J) with jh = first category hit when env e starts drawing at offset o.  jh is tabulated for
   // every reachable (e, o) in parallel (o <= e*J), then one lane chases the table: N dependent LDS byte reads
   // instead of N ballot/popcount/compare rounds.
-  __shared__ unsigned char jh_tab[mt_tab_max(LDSC)];
   __shared__ unsigned short skip_tab[mt_skip_max(LDSC)];
   __shared__ int entry_s[33];
   bool chased = false;
@@ -427,13 +446,13 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     const long tab_entries = (long)N + (long)(J - 1) * N * (N - 1) / 2;
     bool walked = false;
     if constexpr (LDSC == 1) {
-      if (!any_zero && N <= 32 && 4 + 48 * (J - 1) <= 256) {
-        static_assert(mt_tab_max(1) >= 1024 && mt_skip_max(1) >= 1024 + 256, "walk scratch");
+      if (!any_zero && walk_ok) {
+        static_assert(mt_skip_max(1) >= 1024 + 256, "walk scratch");
         switch (J) {
 #define PAAC_WALK_CASE(JJ) \
-  case JJ: mt_group_walks<JJ>(pj_buf, u_buf, jh_tab, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
+  case JJ: mt_group_walks<JJ>(thr_s, u_buf, inv_s, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
           PAAC_WALK_CASE(1) PAAC_WALK_CASE(2) PAAC_WALK_CASE(3) PAAC_WALK_CASE(4) PAAC_WALK_CASE(5)
-          default: mt_group_walks<6>(pj_buf, u_buf, jh_tab, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
+          default: mt_group_walks<6>(thr_s, u_buf, inv_s, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
 #undef PAAC_WALK_CASE
         }
         __syncthreads();
@@ -793,9 +812,18 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
     const int e0 = threadIdx.x < N ? threadIdx.x : 0;
     const float ep_reward0 = ep_reward[e0];
     const int32_t ep_len0 = ep_len[e0];
-    heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,
-                        nullptr);
-    sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
+    if (N * (A + 1) <= 256) {
+      // one (row, output) per thread: the partials are requested now and summed after the sampler's state blocks and
+      // doubles, which need nothing but the state words -- the loads travel while those phases compute
+      float pv[32], bias;
+      heads_partials_issue(partial, ntiles, N * (A + 1), A, ba, bc, pv, bias);
+      auto finish_heads = [&]() { heads_from_issued(pv, bias, ntiles, N, A, lg_s, probs_sh, probs_out, values_out); };
+      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, finish_heads);
+    } else {
+      heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,
+                          nullptr);
+      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
