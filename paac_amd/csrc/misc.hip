@@ -250,23 +250,30 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
   }
 }
 
-// Small shards (up to 32 environments x up to 7 actions) without a table: four groups of 8 environments; group k can be
-// entered at k 8 (J-1) + 1 stream offsets, and one THREAD per (group, entry offset) walks its group from there, deciding
-// each environment's first hit itself (J draws against the environment's J thresholds, all requested before the first
-// compare) and recording the categories it meets -- 8 dependent LDS round trips, all walks side by side (4 + 48 (J-1) <= 256
-// threads).  Then one lane follows the three group exits and every environment picks the record of the walk that really
-// happened.  thr_s / inv_s: the thresholds phase 1 left behind.  Returns the consumed-draw count through *used_s.
-template <int JC>
+// Small shards (up to 32 environments x up to 7 actions) without a table: the environments are cut into groups of QG (8,
+// or 4 where the walks still fit the workgroup); group k can be entered at k QG (J-1) + 1 stream offsets, and one THREAD
+// per (group, entry offset) walks its group from there, deciding each environment's first hit itself (J draws against
+// the environment's J thresholds, all requested before the first compare) and recording the categories it meets -- QG
+// dependent LDS round trips, all walks side by side (groups 0..31/QG: at most 256 threads).  Then one lane follows the
+// group exits and every environment picks the record of the walk that really happened.  thr_s / inv_s: the thresholds
+// phase 1 left behind.  Returns the consumed-draw count through *used_s.
+__host__ __device__ constexpr int mt_walks(const int qg, const int c1) {      // walks of all 32 / qg groups
+  return 32 / qg + qg * c1 * ((32 / qg) * (32 / qg - 1) / 2);
+}
+template <int JC, int QG>
 __device__ __forceinline__ void mt_group_walks(const double* thr_s, const double* u_buf, const unsigned char* inv_s, unsigned short* rec_s,
                                                int* entry_s, int* used_s, const int N, const int D,
                                                int32_t* __restrict__ actions, int16_t* act_lds) {
-  constexpr int QG = 8, C1 = JC - 1;
+  constexpr int C1 = JC - 1, NGRP = 32 / QG;
+  static_assert(mt_walks(QG, C1) <= 256, "one thread per walk");
   const int tid = threadIdx.x;
   MISC_STAMP(5);
-  unsigned char* act_h = reinterpret_cast<unsigned char*>(rec_s);                // [walk <= 256][8 hops]
+  unsigned char* act_h = reinterpret_cast<unsigned char*>(rec_s);                // [walk <= 256][QG hops]
   unsigned short* end_h = rec_s + 1024;                                           // [walk] exit offset
   auto first_walk = [&](const int k) { return k + QG * C1 * (k * (k - 1) / 2); };   // walks of groups 0..k-1
-  const int g = (tid >= first_walk(3)) ? 3 : (tid >= first_walk(2)) ? 2 : (tid >= first_walk(1)) ? 1 : 0;
+  int g = 0;
+#pragma unroll
+  for (int k = 1; k < NGRP; ++k) g = (tid >= first_walk(k)) ? k : g;
   const int h = tid - first_walk(g);
   if (g * QG < N && h < g * QG * C1 + 1) {
     int e = g * QG, o = e + h;
@@ -450,9 +457,9 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
         static_assert(mt_skip_max(1) >= 1024 + 256, "walk scratch");
         switch (J) {
 #define PAAC_WALK_CASE(JJ) \
-  case JJ: mt_group_walks<JJ>(thr_s, u_buf, inv_s, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
+  case JJ: mt_group_walks<JJ, (mt_walks(4, JJ - 1) <= 256 ? 4 : 8)>(thr_s, u_buf, inv_s, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
           PAAC_WALK_CASE(1) PAAC_WALK_CASE(2) PAAC_WALK_CASE(3) PAAC_WALK_CASE(4) PAAC_WALK_CASE(5)
-          default: mt_group_walks<6>(thr_s, u_buf, inv_s, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
+          default: mt_group_walks<6, 8>(thr_s, u_buf, inv_s, skip_tab, entry_s, &any_zero, N, D, actions, act_lds); break;
 #undef PAAC_WALK_CASE
         }
         __syncthreads();
