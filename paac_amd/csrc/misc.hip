@@ -571,42 +571,53 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     }
   }
   MISC_STAMP(6);
-  // phase 4b: one wavefront walks the envs in index order; lane j owns category j
-  if (tid < 64) {
-    const int lane = tid;
-    int o = chased ? any_zero : 0;
-    for (int e = chased ? N : 0; e < N; ++e) {
-      const bool mine = lane < J;
-      const double pj = mine ? pj_buf[(long)e * J + lane] : 0.0;
-      const bool nzl = mine && (pj != 0.0);
-      const unsigned long long nz = __ballot(nzl);
-      const unsigned long long below = (lane == 0) ? 0ull : (nz & ((1ull << lane) - 1ull));
-      bool hit = false;
-      if (nzl) {
-        const double U = u_buf[o + __popcll(below)];
-        if (pj <= 0.5) {
-          hit = U > 1.0 - pj;
-        } else {
-          const double q = 1.0 - pj;
-          hit = !(U > 1.0 - q);
+  // phase 4b (only when the fast paths above did not run): one wavefront walks the envs in index order; lane j owns
+  // category j
+  if (!chased) {
+    if (tid < 64) {
+      const int lane = tid;
+      int o = 0;
+      for (int e = 0; e < N; ++e) {
+        const bool mine = lane < J;
+        const double pj = mine ? pj_buf[(long)e * J + lane] : 0.0;
+        const bool nzl = mine && (pj != 0.0);
+        const unsigned long long nz = __ballot(nzl);
+        const unsigned long long below = (lane == 0) ? 0ull : (nz & ((1ull << lane) - 1ull));
+        bool hit = false;
+        if (nzl) {
+          const double U = u_buf[o + __popcll(below)];
+          if (pj <= 0.5) {
+            hit = U > 1.0 - pj;
+          } else {
+            const double q = 1.0 - pj;
+            hit = !(U > 1.0 - q);
+          }
         }
+        const unsigned long long hm = __ballot(hit);
+        int act, used;
+        if (hm) {
+          act = __ffsll((long long)hm) - 1;
+          used = __popcll(nz & ((2ull << act) - 1ull));
+        } else {
+          act = A - 1;
+          used = __popcll(nz);
+        }
+        if (lane == 0) {
+          actions[e] = act;
+          if (act_lds) act_lds[e] = (int16_t)act;
+        }
+        o += used;
       }
-      const unsigned long long hm = __ballot(hit);
-      int act, used;
-      if (hm) {
-        act = __ffsll((long long)hm) - 1;
-        used = __popcll(nz & ((2ull << act) - 1ull));
-      } else {
-        act = A - 1;
-        used = __popcll(nz);
-      }
-      if (lane == 0) {
-        actions[e] = act;
-        if (act_lds) act_lds[e] = (int16_t)act;
-      }
-      o += used;
+      if (lane == 0) any_zero = o;                       // the consumed-draw count, like the fast paths leave it
     }
-    // write back the stream position in numpy's convention (pos in [0,624], regenerate lazily)
+    __syncthreads();
+  }
+  // Every path has passed a barrier since the actions were written: the caller may read act_lds without another one.
+  // The stream position goes back in numpy's convention (pos in [0,624], regenerate lazily) -- by the LAST wave, so that
+  // the first ones are already back in the caller's bookkeeping meanwhile.
+  if (tid >= 192) {
+    const int lane = tid - 192;
+    const int o = any_zero;
     const uint32_t abs_pos = pos + 2u * (uint32_t)o;
     int fb = (int)(abs_pos / 624u);
     uint32_t np = abs_pos % 624u;
@@ -771,8 +782,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     const int e0 = threadIdx.x < N ? threadIdx.x : 0;
     const float ep_reward0 = ep_reward[e0];
     const int32_t ep_len0 = ep_len[e0];
-    sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);
-    __syncthreads();
+    sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);   // ends past a barrier
     MISC_STAMP(7);
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
                           nullptr);
       sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
     }
-    __syncthreads();
+    // (the sampler body ends past a barrier; its last wave is still writing the stream position back)
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
       synth_bookkeep_with(key, e, act_s[e], thresh, ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
