@@ -829,6 +829,10 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
     const int e0 = threadIdx.x < N ? threadIdx.x : 0;
     const float ep_reward0 = ep_reward[e0];
     const int32_t ep_len0 = ep_len[e0];
+    // ... and the action-independent half of environment e0's bookkeeping
+    const uint32_t key0 = synth_key(seed, env_offset + (uint32_t)e0, id);
+    const uint32_t hr5 = synth_reward_slot(key0);
+    const bool term0 = synth_terminal(key0, thresh);
     if (N * (A + 1) <= 256) {
       // one (row, output) per thread: the partials are requested now and summed after the sampler's state blocks and
       // doubles, which need nothing but the state words -- the loads travel while those phases compute
@@ -842,10 +846,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
       sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
     }
     // (the sampler body ends past a barrier; its last wave is still writing the stream position back)
-    for (int e = threadIdx.x; e < N; e += 256) {
-      const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
-      synth_bookkeep_with(key, e, act_s[e], thresh, ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
-    }
+    if ((int)threadIdx.x < N)       // N <= 64 here: one environment per thread
+      synth_bookkeep_hashed(hr5, term0, e0, act_s[e0], ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
     return;
   }
   synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);

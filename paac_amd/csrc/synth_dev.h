@@ -27,13 +27,15 @@ struct FinishedRing {
 
 // Per-env bookkeeping shared by both paths: emulator_runner.py:30-31 + paac.py:119-138.  ep_reward0 / ep_len0 = the
 // running totals before this step (callers that have something to wait for load them early).
-__device__ __forceinline__ bool synth_bookkeep_with(uint32_t key, int e, int act, uint32_t thresh, float ep_reward0,
-                                                    int32_t ep_len0, float* rewards_out, float* masks_out,
-                                                    float* ep_reward, int32_t* ep_len, FinishedRing* fin) {
+// hr5 = lowbias32(key ^ 0xA511E9B3) % 5 and term = lowbias32(key ^ 0x3C6EF372) < thresh do not depend on the action:
+// a caller that waits for the action computes them first (synth_reward_slot / synth_terminal).
+__device__ __forceinline__ uint32_t synth_reward_slot(uint32_t key) { return lowbias32(key ^ 0xA511E9B3u) % 5u; }
+__device__ __forceinline__ bool synth_terminal(uint32_t key, uint32_t thresh) { return lowbias32(key ^ 0x3C6EF372u) < thresh; }
+__device__ __forceinline__ bool synth_bookkeep_hashed(uint32_t hr5, bool term, int e, int act, float ep_reward0,
+                                                      int32_t ep_len0, float* rewards_out, float* masks_out,
+                                                      float* ep_reward, int32_t* ep_len, FinishedRing* fin) {
   const float table[5] = {-2.f, 0.f, 0.f, 1.f, 3.f};
-  const uint32_t hr = lowbias32(key ^ 0xA511E9B3u);
-  const float r = table[(hr % 5u + (uint32_t)act) % 5u];
-  const bool term = lowbias32(key ^ 0x3C6EF372u) < thresh;
+  const float r = table[(hr5 + (uint32_t)act) % 5u];
   rewards_out[e] = fminf(fmaxf(r, -1.f), 1.f);   // actor_learner.py:95-101
   masks_out[e] = term ? 0.f : 1.f;               // paac.py:119
   const float tot = ep_reward0 + r;
@@ -51,6 +53,12 @@ __device__ __forceinline__ bool synth_bookkeep_with(uint32_t key, int e, int act
     ep_len[e] = len;
   }
   return term;
+}
+__device__ __forceinline__ bool synth_bookkeep_with(uint32_t key, int e, int act, uint32_t thresh, float ep_reward0,
+                                                    int32_t ep_len0, float* rewards_out, float* masks_out,
+                                                    float* ep_reward, int32_t* ep_len, FinishedRing* fin) {
+  return synth_bookkeep_hashed(synth_reward_slot(key), synth_terminal(key, thresh), e, act, ep_reward0, ep_len0, rewards_out,
+                               masks_out, ep_reward, ep_len, fin);
 }
 __device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_t* actions, uint32_t thresh,
                                                float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
