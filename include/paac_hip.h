@@ -252,13 +252,18 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
 /* paac_sample_mt + paac_synth_step (path A) in ONE launch: workgroup 0 samples (numpy-parity MT19937 stream) and does
  * the per-env bookkeeping while the other workgroups shift the observation stacks (stack_out2, nullable: a second copy
  * of the new stacks, like paac_synth_step's).  Limit: N*(A-1) <= 2304 (covers 256 environments x 4 actions and
- * 128 x 18). */
+ * 128 x 18).
+ * walk_scratch (nullable): device memory of paac_walk_scratch_bytes(N, A) bytes, ZERO-INITIALISED once by the caller, then
+ * left to the library and lent to every call of the same (N, A) in one stream order.  With it the large shards (more than
+ * 64 environments or 1024 draws) spread the sampler's walk over several workgroups of the launch (same actions, same
+ * stream position; about 4x shorter); without it one workgroup walks all environments. */
 #define PAAC_FUSED_SAMPLE_MAX_DRAWS 2304
+int64_t paac_walk_scratch_bytes(int N, int A);
 int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
                               uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
-                              paac_stream_t stream);
+                              void* walk_scratch, int64_t walk_scratch_bytes, paac_stream_t stream);
 
 /* hipGraph helpers: capture every launch issued on `stream` between begin/end, replay with launch. */
 int paac_graph_begin(paac_stream_t stream);

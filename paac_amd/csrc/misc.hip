@@ -317,6 +317,126 @@ __device__ __forceinline__ void mt_group_walks(const double* thr_s, const double
   }
 }
 
+// Large shards (256 environments x 4 actions, 128 x 18): the same group walks spread over SEVERAL workgroups of the launch.
+// Every sampler workgroup rebuilds thresholds and doubles for itself (cheap next to a serial walk over all environments),
+// takes 256 of the (group of 8 environments, entry offset) walks, and leaves their records in global memory; the workgroup
+// that takes the last ticket follows the group exits, reads every environment's category out of the record of the walk
+// that really happened, and goes on as the one sampler workgroup used to (stream position, bookkeeping).  Tickets are a
+// counter that is never reset: every launch adds W to it.
+struct MultiWalk {
+  unsigned char* rec;         // [walks][8] categories met
+  unsigned short* exits;      // [walks] stream offset each walk leaves its group at
+  unsigned int* counter;
+  int W;                      // sampler workgroups of the launch; 0: single-workgroup sampler
+};
+constexpr int MW_G = 8;
+__host__ __device__ inline long mw_first_walk(const int k, const int c1) { return k + (long)MW_G * c1 * ((long)k * (k - 1) / 2); }
+__host__ __device__ inline long mw_walks(const int N, const int A) { return mw_first_walk((N + MW_G - 1) / MW_G, A - 2); }
+
+// one hop of a walk: first category hit by environment e when it starts drawing at offset o (J = JC > 0, or Jdyn)
+template <int JC>
+__device__ __forceinline__ int mw_first_hit(const double* thr_s, const unsigned char* inv_s, const double* u_buf, const int e,
+                                            const int o, const int D, const int Jdyn) {
+  if constexpr (JC > 0) {
+    double U[JC], T[JC];
+    int I[JC];
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      U[j] = u_buf[o + j < D ? o + j : D - 1];
+      T[j] = thr_s[e * JC + j];
+      I[j] = inv_s[e * JC + j];
+    }
+    int jh = JC;
+#pragma unroll
+    for (int j = JC - 1; j >= 0; --j)
+      if ((U[j] > T[j]) != (I[j] != 0)) jh = j;
+    return jh;
+  } else {
+    const int J = Jdyn;
+    int jh = J;
+    for (int j0 = 0; j0 < J && jh == J; j0 += 4) {      // four categories per round trip; most walks hit early
+      double U[4], T[4];
+      int I[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q < J ? j0 + q : J - 1;
+        U[q] = u_buf[o + j < D ? o + j : D - 1];
+        T[q] = thr_s[e * J + j];
+        I[q] = inv_s[e * J + j];
+      }
+#pragma unroll
+      for (int q = 3; q >= 0; --q)
+        if (j0 + q < J && (U[q] > T[q]) != (I[q] != 0)) jh = j0 + q;
+    }
+    return jh;
+  }
+}
+
+// Returns true in the workgroup that took the last ticket (actions written, *used_s = draws consumed), false elsewhere.
+template <int JC>
+__device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double* thr_s, const unsigned char* inv_s,
+                                               const double* u_buf, unsigned short* exits_lds, int* entry_s, int* used_s,
+                                               const int N, const int J, const int D, int32_t* __restrict__ actions,
+                                               int16_t* act_lds) {
+  const int tid = threadIdx.x;
+  const int c1 = J - 1, NG = (N + MW_G - 1) / MW_G;
+  const long nwk = mw_first_walk(NG, c1);
+  const long wid = (long)blockIdx.x * 256 + tid;
+  if (wid < nwk) {
+    // group k = the largest with first_walk(k) <= wid:  first_walk(k) = a k^2 + (1 - a) k,  a = 4 (J - 1)
+    int k;
+    if (c1 == 0) {
+      k = (int)wid;
+    } else {
+      const float a = 4.0f * (float)c1;
+      k = (int)((sqrtf((1.f - a) * (1.f - a) + 4.f * a * (float)wid) - (1.f - a)) / (2.f * a));
+      k = k < 0 ? 0 : (k > NG - 1 ? NG - 1 : k);
+      while (k > 0 && mw_first_walk(k, c1) > wid) --k;
+      while (k < NG - 1 && mw_first_walk(k + 1, c1) <= wid) ++k;
+    }
+    int e = k * MW_G, o = e + (int)(wid - mw_first_walk(k, c1));
+    unsigned int lo = 0, hi = 0;                         // the 8 categories met, one byte each
+    for (int hop = 0; hop < MW_G; ++hop) {
+      if (e < N) {
+        const int jh = mw_first_hit<JC>(thr_s, inv_s, u_buf, e, o, D, J);
+        if (hop < 4) lo |= (unsigned int)jh << (8 * hop);
+        else hi |= (unsigned int)jh << (8 * (hop - 4));
+        o += (jh + 1 < J) ? jh + 1 : J;
+        ++e;
+      }
+    }
+    reinterpret_cast<uint2*>(mw.rec)[wid] = make_uint2(lo, hi);
+    mw.exits[wid] = (unsigned short)o;
+  }
+  __threadfence();
+  __syncthreads();
+  __shared__ int last_s;
+  if (tid == 0) last_s = (atomicAdd(mw.counter, 1u) % (unsigned int)mw.W) == (unsigned int)(mw.W - 1);
+  __syncthreads();
+  if (!last_s) return false;
+  __threadfence();
+  for (long i = tid; i < nwk; i += 256) exits_lds[i] = __builtin_nontemporal_load(mw.exits + i);
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int k = 0; k < NG; ++k) {
+      const long w = mw_first_walk(k, c1) + o - k * MW_G;      // the walk of group k that really happens
+      entry_s[k] = (int)w;
+      o = exits_lds[w];
+    }
+    *used_s = o;
+  }
+  __syncthreads();
+  for (int e = tid; e < N; e += 256) {
+    const int k = e / MW_G;
+    const int jh = __builtin_nontemporal_load(mw.rec + (long)entry_s[k] * MW_G + (e - k * MW_G));
+    actions[e] = jh;                                     // jh == J  <=>  no hit  <=>  action A-1 = J
+    if (act_lds) act_lds[e] = (int16_t)jh;
+  }
+  __syncthreads();
+  return true;
+}
+
 // probs_lds (LDSC > 0 only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
 // stw_pre (with probs_lds): the caller requested the 625 state words (3 per thread, clamped index) before producing them.
 // probs_hook (with probs_lds): produces the probabilities in probs_lds and ends with a barrier.  It is called AFTER the
@@ -326,12 +446,12 @@ struct NoProbsHook {
   __device__ __forceinline__ void operator()() const {}
 };
 template <int LDSC, class HOOK = NoProbsHook>
-__device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, int N, int A,
+__device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
                                                double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
                                                int32_t* __restrict__ actions, int16_t* act_lds,
                                                const float* probs_lds = nullptr, const uint32_t* stw_pre = nullptr,
-                                               const HOOK probs_hook = HOOK()) {
+                                               const HOOK probs_hook = HOOK(), const MultiWalk mw = MultiWalk{nullptr, nullptr, nullptr, 0}) {
   constexpr bool HOOKED = !__is_same(HOOK, NoProbsHook);
   MISC_STAMP(0);
   constexpr bool LDSPATH = LDSC > 0;
@@ -383,10 +503,11 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
   const int nblk = (int)((pos + 2u * (uint32_t)D) / 624u) + 1;
   // the walks of the small shards (mt_group_walks) want thresholds: phase 1 leaves them behind too
   __shared__ __attribute__((aligned(8))) unsigned char jh_tab[mt_tab_max(LDSC)];
-  const bool walk_ok = LDSC == 1 && N <= 32 && 4 + 48 * (J - 1) <= 256;
+  const bool multi = LDSC == 2 && mw.W > 0;          // group walks spread over mw.W workgroups of the launch
+  const bool walk_ok = (LDSC == 1 && N <= 32 && 4 + 48 * (J - 1) <= 256) || multi;
   double* thr_s = reinterpret_cast<double*>(jh_tab);           // [D <= 1024]   (the first-hit table is not built then)
-  unsigned char* inv_s = jh_tab + (LDSC == 1 ? 8192 : 0);      // [D]
-  static_assert(LDSC != 1 || mt_tab_max(1) >= 8192 + 1024, "threshold arrays reuse the table's LDS");
+  unsigned char* inv_s = jh_tab + (LDSC == 0 ? 0 : 8 * mt_lds_d(LDSC));      // [D]
+  static_assert(LDSC == 0 || mt_tab_max(LDSC) >= 9 * mt_lds_d(LDSC), "threshold arrays reuse the table's LDS");
   // phase 1: conditional probabilities p_j / remaining_j, one (env, category) per thread: the running
   // `remaining` is rebuilt with the reference's sequential fp64 subtraction order (cheap), so that only ONE fp64
   // division sits on each thread's critical path instead of J in a row
@@ -452,6 +573,27 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
     // env e can only start at offsets e .. e J (every earlier env drew between 1 and J doubles)
     const long tab_entries = (long)N + (long)(J - 1) * N * (N - 1) / 2;
     bool walked = false;
+    if constexpr (LDSC == 2) {
+      if (multi) {
+        if (any_zero) {
+          if (blockIdx.x != 0) return false;          // the rare exact-zero case: workgroup 0 alone, the serial way
+        } else {
+          unsigned short* exits_lds = reinterpret_cast<unsigned short*>(jh_tab + 9 * mt_lds_d(2));
+          static_assert(mt_tab_max(2) >= 9 * MT_LDS_D2 + 2 * 16384, "exit offsets of up to 16 k walks next to the thresholds");
+          bool owner;
+          switch (J) {
+            case 1: owner = mt_multi_walks<1>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+            case 2: owner = mt_multi_walks<2>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+            case 3: owner = mt_multi_walks<3>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+            case 5: owner = mt_multi_walks<5>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+            default: owner = mt_multi_walks<0>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+          }
+          if (!owner) return false;
+          walked = true;
+          chased = true;
+        }
+      }
+    }
     if constexpr (LDSC == 1) {
       if (!any_zero && walk_ok) {
         static_assert(mt_skip_max(1) >= 1024 + 256, "walk scratch");
@@ -629,6 +771,7 @@ __device__ __forceinline__ void sample_mt_body(const float* __restrict__ probs, 
       for (int i = lane; i < 624; i += 64) mt_state[i] = blocks[(long)fb * 624 + i];
     if (lane == 0) mt_state[624] = np;
   }
+  return true;
 }
 
 template <int LDSC>
@@ -774,15 +917,19 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
                                                               uint32_t* __restrict__ stack_out,
                                                               uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                               float* masks_out, float* ep_reward, int32_t* ep_len,
-                                                              FinishedRing* fin) {
+                                                              FinishedRing* fin, const MultiWalk mw) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
-  if (blockIdx.x == 0) {
+  const int samplers = mw.W > 0 ? mw.W : 1;          // sampler workgroups in front of the shift workgroups
+  if ((int)blockIdx.x < samplers) {
     __shared__ int16_t act_s[mt_lds_d(LDSC)];
     // the running episode totals do not depend on the sampler: request them before it (first 256 environments)
     const int e0 = threadIdx.x < N ? threadIdx.x : 0;
     const float ep_reward0 = ep_reward[e0];
     const int32_t ep_len0 = ep_len[e0];
-    sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s);   // ends past a barrier
+    // (ends past a barrier; with several sampler workgroups only the one that finishes the walks goes on)
+    if (!sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, nullptr, nullptr, NoProbsHook(),
+                              mw))
+      return;
     MISC_STAMP(7);
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
@@ -796,9 +943,9 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
   }
   if constexpr (LDSC == 2) {
     for (int band = 0; band < PRE_BANDS; ++band)
-      synth_shift_band(seed, env_offset, id, thresh, ((int)blockIdx.x - 1) * PRE_BANDS + band, stack_in, stack_out, stack_out2);
+      synth_shift_band(seed, env_offset, id, thresh, ((int)blockIdx.x - samplers) * PRE_BANDS + band, stack_in, stack_out, stack_out2);
   } else {
-    synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
+    synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - samplers, stack_in, stack_out, stack_out2);
   }
 }
 
@@ -1512,11 +1659,17 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
   return 0;
 }
 
+int64_t paac_walk_scratch_bytes(int N, int A) {
+  if (N <= 0 || A < 2) return 0;
+  const long nwk = mw_walks(N, A);
+  return 64 + ((nwk * 2 + 63) / 64) * 64 + nwk * 8;
+}
+
 int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
                               uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
-                              paac_stream_t stream) {
+                              void* walk_scratch, int64_t walk_scratch_bytes, paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
   PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D2, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
                "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D2);
@@ -1526,14 +1679,28 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
   // small shards: the small-LDS sampler, one shift workgroup per band; beyond 1024 draws or 64 environments (where the
   // two-level chase needs the large first-hit table): the large-LDS sampler, one shift workgroup per environment
   const bool large = (int64_t)N * (A - 1) > MT_LDS_D || (long)N + (long)(A - 2) * N * (N - 1) / 2 > MT_TAB_MAX;
+  MultiWalk mw{nullptr, nullptr, nullptr, 0};
+  if (large && walk_scratch != nullptr) {
+    // the caller lent a (zero-initialised, otherwise untouched) scratch: the walks go out over several workgroups
+    const long nwk = mw_walks(N, A);
+    PAAC_REQUIRE(walk_scratch_bytes >= paac_walk_scratch_bytes(N, A), "paac_sample_mt_synth_step: walk scratch of %ld bytes, "
+                 "%ld needed (paac_walk_scratch_bytes)", (long)walk_scratch_bytes, (long)paac_walk_scratch_bytes(N, A));
+    if (nwk <= 16384 && N <= 256) {
+      char* base = static_cast<char*>(walk_scratch);
+      mw.counter = reinterpret_cast<unsigned int*>(base);
+      mw.exits = reinterpret_cast<unsigned short*>(base + 64);
+      mw.rec = reinterpret_cast<unsigned char*>(base + 64 + ((nwk * 2 + 63) / 64) * 64);
+      mw.W = (int)((nwk + 255) / 256);
+    }
+  }
   if (large)
-    launch_k(synth_step_a_mt_kernel<2>, dim3(1 + N), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
-             actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
-             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
+    launch_k(synth_step_a_mt_kernel<2>, dim3((mw.W > 0 ? mw.W : 1) + N), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
+             mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw);
   else
     launch_k(synth_step_a_mt_kernel<1>, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
              actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
-             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished);
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -403,8 +403,15 @@ ACT_STEP_MAX_DRAWS = 1024
 ACT_STEP_MAX_ENVS = 64
 
 
+def walk_scratch(N, A, device):
+    """Zero-initialised scratch that lets the large shards' sampler spread its walk over several workgroups
+    (include/paac_hip.h: paac_sample_mt_synth_step); lend the same tensor to every call of one (N, A)."""
+    return torch.zeros(int(_lib.load().paac_walk_scratch_bytes(int(N), int(A))), dtype=torch.uint8, device=device)
+
+
 def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_threshold, step_base_dev, step_offset,
-                         stack_in, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None, stack_out2=None):
+                         stack_in, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None, stack_out2=None,
+                         walk_scratch=None):
     N, A = probs.shape
     if N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
         raise ValueError("fused sampler+env step supports N*(A-1) <= %d" % FUSED_SAMPLE_MAX_DRAWS)
@@ -421,7 +428,9 @@ def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_th
         _ptr(stack_out2, torch.uint8, N * 28224, "stack_out2", True),
         _ptr(rewards_out, torch.float32, N, "rewards_out"), _ptr(masks_out, torch.float32, N, "masks_out"),
         _ptr(ep_reward, torch.float32, N, "ep_reward"), _ptr(ep_len, torch.int32, N, "ep_len"),
-        ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),
+        ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0),
+        ctypes.c_void_p(walk_scratch.data_ptr()) if walk_scratch is not None else ctypes.c_void_p(0),
+        int(walk_scratch.numel()) if walk_scratch is not None else 0, _stream()),
         "paac_sample_mt_synth_step")
 
 

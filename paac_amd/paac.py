@@ -58,6 +58,8 @@ class DeviceRollout(object):
         self.tick = torch.zeros((1,), dtype=torch.int64, device=dev)          # env steps taken (per env)
         self.global_step_dev = torch.full((1,), int(L.global_step), dtype=torch.int64, device=dev)
         self.raw = None
+        # lets the large shards' sampler spread its walk over several workgroups (hip_ops.sample_mt_synth_step)
+        self.walk_scratch = hip_ops.walk_scratch(N, A, dev) if N * (A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS else None
         if env_spec.get("raw_frames"):
             self.raw = torch.zeros((N, 2, hip_ops.RAW_H, hip_ops.RAW_W), dtype=torch.uint8, device=dev)
         if sampler == "numpy":
@@ -115,7 +117,7 @@ class DeviceRollout(object):
                 hip_ops.sample_mt_synth_step(self.probs, self.mt_state, self.actions[t], self.env_spec["seed"],
                                              self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
                                              st[t], st[t + 1], self.rewards[t], self.masks[t], self.ep_reward,
-                                             self.ep_len, self.finished, stack_out2=wrap)
+                                             self.ep_len, self.finished, stack_out2=wrap, walk_scratch=self.walk_scratch)
                 continue
             if self.sampler == "numpy":
                 L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])

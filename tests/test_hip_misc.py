@@ -314,11 +314,14 @@ def test_act_step_equals_separate_calls(arch, A, N, managed):
     ctx.close()
 
 
-@pytest.mark.parametrize("N,A", [(32, 4), (256, 4), (128, 18), (96, 6)])
-def test_fused_sampler_env_step_equals_separate_calls(N, A):
+@pytest.mark.parametrize("N,A,multi", [(32, 4, False), (256, 4, False), (128, 18, False), (96, 6, False),
+                                       (256, 4, True), (128, 18, True), (96, 6, True), (200, 3, True), (65, 2, True),
+                                       (32, 4, True)])
+def test_fused_sampler_env_step_equals_separate_calls(N, A, multi):
     """paac_sample_mt_synth_step (small and large-LDS variants: 256 environments x 4 actions = two-level table chase with
-    one shift workgroup per environment; 128 x 18 = lane walk) == paac_sample_mt + paac_synth_step, bit for bit, and the
-    actions are numpy's."""
+    one shift workgroup per environment; 128 x 18 = lane walk; multi: the group walks of the large shards spread over
+    several workgroups through the caller's walk scratch) == paac_sample_mt + paac_synth_step, bit for bit, and the actions
+    are numpy's."""
     from paac_amd import hip_ops
     from paac_amd.synthetic import terminal_threshold
     env_seed, off, thr = 9, 2, terminal_threshold(0.2)
@@ -341,14 +344,15 @@ def test_fused_sampler_env_step_equals_separate_calls(N, A):
     a, b = fresh(), fresh()
     ref_rs = np.random.RandomState(31)
     scratch = hip_ops.sample_mt_scratch(N, A, "cuda")
-    for step in range(4):
+    walk = hip_ops.walk_scratch(N, A, "cuda") if multi else None
+    for step in range(6 if multi else 4):
         logits = gen.randn(N, A) * 1.5
         p = np.exp(logits - logits.max(1, keepdims=True))
         p = np.maximum(p / p.sum(1, keepdims=True), 1e-6).astype(np.float32)
         p = (p / p.sum(1, keepdims=True)).astype(np.float32)
         pd = dev(p)
         hip_ops.sample_mt_synth_step(pd, a["mt"], a["act"], env_seed, off, thr, a["tick"], 0, a["s0"], a["s1"], a["rew"],
-                                     a["msk"], a["ep_r"], a["ep_l"], a["fin"], stack_out2=a["s2"])
+                                     a["msk"], a["ep_r"], a["ep_l"], a["fin"], stack_out2=a["s2"], walk_scratch=walk)
         hip_ops.sample_mt(pd, b["mt"], scratch, b["act"])
         hip_ops.synth_step(env_seed, off, b["act"], thr, b["tick"], 0, b["s0"], b["s1"], b["rew"], b["msk"], b["ep_r"],
                            b["ep_l"], b["fin"], stack_out2=b["s2"])

@@ -19,6 +19,7 @@ s0 = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device=dev); s1 = torch.zero
 rew = torch.zeros(N, device=dev); msk = torch.zeros(N, device=dev); epr = torch.zeros(N, device=dev)
 epl = torch.zeros(N, dtype=torch.int32, device=dev); fin = torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device=dev)
 tick = torch.zeros(1, dtype=torch.int64, device=dev)
+walk = hip_ops.walk_scratch(N, A, dev) if os.environ.get("PROBE_MULTI", "") == "1" else None
 names = ["entry->loads landed", "phase 1 (cond. probabilities)", "phase 2 (state blocks)", "phase 3 (doubles)",
          "table fill", "chase", "write-back", "bookkeeping"]
 acc = np.zeros(8)
@@ -26,7 +27,8 @@ reps = 50
 for r in range(reps + 5):
     probs = torch.softmax(torch.randn(N, A, device=dev), dim=1)    # cold-ish probabilities each time
     torch.cuda.synchronize()
-    hip_ops.sample_mt_synth_step(probs, mt, act, 3, 0, terminal_threshold(0.01), tick, 0, s0, s1, rew, msk, epr, epl, fin)
+    hip_ops.sample_mt_synth_step(probs, mt, act, 3, 0, terminal_threshold(0.01), tick, 0, s0, s1, rew, msk, epr, epl, fin,
+                                 walk_scratch=walk)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().astype(np.float64)
     if r >= 5:
