@@ -333,6 +333,17 @@ constexpr int MW_G = 8;
 __host__ __device__ inline long mw_first_walk(const int k, const int c1) { return k + (long)MW_G * c1 * ((long)k * (k - 1) / 2); }
 __host__ __device__ inline long mw_walks(const int N, const int A) { return mw_first_walk((N + MW_G - 1) / MW_G, A - 2); }
 
+// group of walk `wid`: the largest k with first_walk(k) <= wid  (first_walk(k) = a k^2 + (1 - a) k, a = 4 (J - 1))
+__device__ __forceinline__ int mw_group_of(const long wid, const int c1, const int NG) {
+  if (c1 == 0) return (int)wid;
+  const float a = 4.0f * (float)c1;
+  int k = (int)((sqrtf((1.f - a) * (1.f - a) + 4.f * a * (float)wid) - (1.f - a)) / (2.f * a));
+  k = k < 0 ? 0 : (k > NG - 1 ? NG - 1 : k);
+  while (k > 0 && mw_first_walk(k, c1) > wid) --k;
+  while (k < NG - 1 && mw_first_walk(k + 1, c1) <= wid) ++k;
+  return k;
+}
+
 // one hop of a walk: first category hit by environment e when it starts drawing at offset o (J = JC > 0, or Jdyn)
 template <int JC>
 __device__ __forceinline__ int mw_first_hit(const double* thr_s, const unsigned char* inv_s, const double* u_buf, const int e,
@@ -383,17 +394,7 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
   const long nwk = mw_first_walk(NG, c1);
   const long wid = (long)blockIdx.x * 256 + tid;
   if (wid < nwk) {
-    // group k = the largest with first_walk(k) <= wid:  first_walk(k) = a k^2 + (1 - a) k,  a = 4 (J - 1)
-    int k;
-    if (c1 == 0) {
-      k = (int)wid;
-    } else {
-      const float a = 4.0f * (float)c1;
-      k = (int)((sqrtf((1.f - a) * (1.f - a) + 4.f * a * (float)wid) - (1.f - a)) / (2.f * a));
-      k = k < 0 ? 0 : (k > NG - 1 ? NG - 1 : k);
-      while (k > 0 && mw_first_walk(k, c1) > wid) --k;
-      while (k < NG - 1 && mw_first_walk(k + 1, c1) <= wid) ++k;
-    }
+    const int k = mw_group_of(wid, c1, NG);
     int e = k * MW_G, o = e + (int)(wid - mw_first_walk(k, c1));
     unsigned int lo = 0, hi = 0;                         // the 8 categories met, one byte each
     for (int hop = 0; hop < MW_G; ++hop) {
@@ -511,8 +512,8 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   // phase 1: conditional probabilities p_j / remaining_j, one (env, category) per thread: the running
   // `remaining` is rebuilt with the reference's sequential fp64 subtraction order (cheap), so that only ONE fp64
   // division sits on each thread's critical path instead of J in a row
-  auto phase1 = [&]() {
-    for (int d = tid; d < D; d += 256) {
+  auto phase1 = [&](const int e_lo, const int e_hi) {      // environments [e_lo, e_hi)
+    for (int d = e_lo * J + tid; d < e_hi * J; d += 256) {
       const int e = d / J, j = d - e * J;
       double remaining = 1.0;
       for (int i = 0; i < j; ++i)
@@ -528,7 +529,24 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       }
     }
   };
-  if constexpr (!HOOKED) phase1();
+  // several sampler workgroups: each needs the thresholds of the environments ITS walks visit only; whether some
+  // conditional probability is exactly zero (cond == 0  <=>  float32(p - epsneg) == 0) is read off the raw probabilities
+  int p1_lo = 0, p1_hi = N;
+  if (multi) {
+    for (int i = tid; i < N * A; i += 256)
+      if (i % A < J && (pr[i] - 5.9604644775390625e-08f) == 0.0f) any_zero = 1;
+    const int NGm = (N + MW_G - 1) / MW_G;
+    const long nwk = mw_first_walk(NGm, J - 1);
+    const long w0 = (long)blockIdx.x * 256, w1 = w0 + 255 < nwk - 1 ? w0 + 255 : nwk - 1;
+    if (w0 < nwk) {
+      p1_lo = mw_group_of(w0, J - 1, NGm) * MW_G;
+      p1_hi = (mw_group_of(w1, J - 1, NGm) + 1) * MW_G;
+      p1_hi = p1_hi < N ? p1_hi : N;
+    } else {
+      p1_hi = 0;
+    }
+  }
+  if constexpr (!HOOKED) phase1(p1_lo, p1_hi);
   MISC_STAMP(2);
   // phase 2: successive MT19937 state blocks
   if constexpr (!LDSPATH) {
@@ -558,7 +576,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   __syncthreads();
   if constexpr (HOOKED) {
     probs_hook();            // ends with a barrier: the probabilities are in LDS
-    phase1();
+    phase1(p1_lo, p1_hi);
     __syncthreads();
   }
   MISC_STAMP(4);
@@ -577,6 +595,8 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       if (multi) {
         if (any_zero) {
           if (blockIdx.x != 0) return false;          // the rare exact-zero case: workgroup 0 alone, the serial way
+          phase1(0, N);
+          __syncthreads();
         } else {
           unsigned short* exits_lds = reinterpret_cast<unsigned short*>(jh_tab + 9 * mt_lds_d(2));
           static_assert(mt_tab_max(2) >= 9 * MT_LDS_D2 + 2 * 16384, "exit offsets of up to 16 k walks next to the thresholds");
@@ -1685,7 +1705,9 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
     const long nwk = mw_walks(N, A);
     PAAC_REQUIRE(walk_scratch_bytes >= paac_walk_scratch_bytes(N, A), "paac_sample_mt_synth_step: walk scratch of %ld bytes, "
                  "%ld needed (paac_walk_scratch_bytes)", (long)walk_scratch_bytes, (long)paac_walk_scratch_bytes(N, A));
-    if (nwk <= 16384 && N <= 256) {
+    // (up to 9 actions: with more, a hop of a walk costs too many compares -- 128 x 18 measured slower than the one-workgroup
+    // lane walk -- and the scratch is left alone)
+    if (nwk <= 16384 && N <= 256 && A <= 9) {
       char* base = static_cast<char*>(walk_scratch);
       mw.counter = reinterpret_cast<unsigned int*>(base);
       mw.exits = reinterpret_cast<unsigned short*>(base + 64);
