@@ -962,8 +962,11 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     return;
   }
   if constexpr (LDSC == 2) {
-    for (int band = 0; band < PRE_BANDS; ++band)
-      synth_shift_band(seed, env_offset, id, thresh, ((int)blockIdx.x - samplers) * PRE_BANDS + band, stack_in, stack_out, stack_out2);
+    // every workgroup of this launch reserves the sampler's LDS, so a CU holds one: the (environment, band) units are dealt
+    // over as many shift workgroups as fit beside the sampler workgroups in ONE round of the CUs
+    const int nshift = (int)gridDim.x - samplers;
+    for (int u = (int)blockIdx.x - samplers; u < N * PRE_BANDS; u += nshift)
+      synth_shift_band(seed, env_offset, id, thresh, u, stack_in, stack_out, stack_out2);
   } else {
     synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - samplers, stack_in, stack_out, stack_out2);
   }
@@ -1715,8 +1718,11 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
       mw.W = (int)((nwk + 255) / 256);
     }
   }
+  const int samplers = mw.W > 0 ? mw.W : 1;
+  int nshift = N * PRE_BANDS;                       // large path: one round of the 256 CUs (one workgroup per CU there)
+  if (nshift > 256 - samplers) nshift = 256 - samplers > 32 ? 256 - samplers : 32;
   if (large)
-    launch_k(synth_step_a_mt_kernel<2>, dim3((mw.W > 0 ? mw.W : 1) + N), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
+    launch_k(synth_step_a_mt_kernel<2>, dim3(samplers + nshift), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
              mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw);
   else
