@@ -322,7 +322,8 @@ __device__ __forceinline__ void mt_group_walks(const double* thr_s, const double
 // takes 256 of the (group of 8 environments, entry offset) walks, and leaves their records in global memory; the workgroup
 // that takes the last ticket follows the group exits, reads every environment's category out of the record of the walk
 // that really happened, and goes on as the one sampler workgroup used to (stream position, bookkeeping).  Tickets are a
-// counter that is never reset: every launch adds W to it.
+// counter that is never reset: every launch adds W to it (2^32 tickets = more than 10^8 launches for any W here; one
+// scratch per (N, A)).
 struct MultiWalk {
   unsigned char* rec;         // [walks][8] categories met
   unsigned short* exits;      // [walks] stream offset each walk leaves its group at
