@@ -12,7 +12,7 @@ __device__ unsigned long long* g_misc_stamps = nullptr;   // diagnostic build: p
 #define MISC_STAMP(i)                                                                       \
   do {                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
-    if (g_misc_stamps && threadIdx.x == 0) g_misc_stamps[(i)] = (unsigned long long)clock64(); \
+    if (g_misc_stamps && threadIdx.x == 0) g_misc_stamps[(i)] = (unsigned long long)wall_clock64(); \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
 #else
@@ -410,15 +410,26 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
     reinterpret_cast<uint2*>(mw.rec)[wid] = make_uint2(lo, hi);
     mw.exits[wid] = (unsigned short)o;
   }
-  __threadfence();
+  MISC_STAMP(9);
+  // hand-off: the barrier makes the workgroup's records visible to its thread 0, whose device-scope release (fence, then the
+  // ticket) publishes them -- one fence per workgroup, not one per thread; the same on the acquiring side
   __syncthreads();
   __shared__ int last_s;
-  if (tid == 0) last_s = (atomicAdd(mw.counter, 1u) % (unsigned int)mw.W) == (unsigned int)(mw.W - 1);
+  if (tid == 0) {
+    __threadfence();
+    last_s = (atomicAdd(mw.counter, 1u) % (unsigned int)mw.W) == (unsigned int)(mw.W - 1);
+    if (last_s) __threadfence();
+  }
   __syncthreads();
   if (!last_s) return false;
-  __threadfence();
-  for (long i = tid; i < nwk; i += 256) exits_lds[i] = __builtin_nontemporal_load(mw.exits + i);
+  MISC_STAMP(10);
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(mw.exits);       // 8 exit offsets per load (the scratch is padded)
+    uint4* dst = reinterpret_cast<uint4*>(exits_lds);
+    for (long i = tid; i < (nwk + 7) / 8; i += 256) dst[i] = src[i];
+  }
   __syncthreads();
+  MISC_STAMP(11);
   if (tid == 0) {
     int o = 0;
     for (int k = 0; k < NG; ++k) {
@@ -429,6 +440,7 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
     *used_s = o;
   }
   __syncthreads();
+  MISC_STAMP(12);
   for (int e = tid; e < N; e += 256) {
     const int k = e / MW_G;
     const int jh = __builtin_nontemporal_load(mw.rec + (long)entry_s[k] * MW_G + (e - k * MW_G));
@@ -504,7 +516,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   const float* pr = LDSPATH ? (probs_lds ? probs_lds : probs_s) : probs;
   const int nblk = (int)((pos + 2u * (uint32_t)D) / 624u) + 1;
   // the walks of the small shards (mt_group_walks) want thresholds: phase 1 leaves them behind too
-  __shared__ __attribute__((aligned(8))) unsigned char jh_tab[mt_tab_max(LDSC)];
+  __shared__ __attribute__((aligned(16))) unsigned char jh_tab[mt_tab_max(LDSC)];
   const bool multi = LDSC == 2 && mw.W > 0;          // group walks spread over mw.W workgroups of the launch
   const bool walk_ok = (LDSC == 1 && N <= 32 && 4 + 48 * (J - 1) <= 256) || multi;
   double* thr_s = reinterpret_cast<double*>(jh_tab);           // [D <= 1024]   (the first-hit table is not built then)

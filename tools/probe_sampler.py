@@ -36,3 +36,7 @@ for r in range(reps + 5):
 for n, v in zip(names, acc / reps):
     print("%-32s %8.0f cycles" % (n, v))
 print("%-32s %8.0f cycles" % ("total (entry -> end)", acc.sum() / reps))
+if walk is not None:      # stamped build: wall-clock ticks (10 ns) of the workgroup that took the last ticket
+    w = st[[0, 1, 2, 3, 4, 9, 10, 11, 12, 6, 7, 8]]
+    print("multi (last call, 10 ns ticks): loads %d | p1 %d | p2 %d | p3 %d | walks %d | ticket %d | fence+exits %d | chase %d "
+          "| actions %d | writeback %d | bookkeeping %d" % tuple(np.diff(w)))
