@@ -366,18 +366,19 @@ __device__ __forceinline__ int mw_first_hit(const double* thr_s, const unsigned 
   } else {
     const int J = Jdyn;
     int jh = J;
-    for (int j0 = 0; j0 < J && jh == J; j0 += 4) {      // four categories per round trip; most walks hit early
-      double U[4], T[4];
-      int I[4];
+    constexpr int CH = 6;                                // categories per round trip; a wave scans until its last walk has hit
+    for (int j0 = 0; j0 < J && jh == J; j0 += CH) {
+      double U[CH], T[CH];
+      int I[CH];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < CH; ++q) {
         const int j = j0 + q < J ? j0 + q : J - 1;
         U[q] = u_buf[o + j < D ? o + j : D - 1];
         T[q] = thr_s[e * J + j];
         I[q] = inv_s[e * J + j];
       }
 #pragma unroll
-      for (int q = 3; q >= 0; --q)
+      for (int q = CH - 1; q >= 0; --q)
         if (j0 + q < J && (U[q] > T[q]) != (I[q] != 0)) jh = j0 + q;
     }
     return jh;
@@ -1721,9 +1722,7 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
     const long nwk = mw_walks(N, A);
     PAAC_REQUIRE(walk_scratch_bytes >= paac_walk_scratch_bytes(N, A), "paac_sample_mt_synth_step: walk scratch of %ld bytes, "
                  "%ld needed (paac_walk_scratch_bytes)", (long)walk_scratch_bytes, (long)paac_walk_scratch_bytes(N, A));
-    // (up to 9 actions: with more, a hop of a walk costs too many compares -- 128 x 18 measured slower than the one-workgroup
-    // lane walk -- and the scratch is left alone)
-    if (nwk <= 16384 && N <= 256 && A <= 9) {
+    if (nwk <= 16384 && N <= 256 && A <= 32) {
       char* base = static_cast<char*>(walk_scratch);
       mw.counter = reinterpret_cast<unsigned int*>(base);
       mw.exits = reinterpret_cast<unsigned short*>(base + 64);
