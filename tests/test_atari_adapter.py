@@ -1,7 +1,9 @@
-"""The Atari adapter (paac_amd/atari_emulator.py) against the reference's episode semantics
-(atari_emulator.py:60-112) restated with the oracle's pools, and its raw-screen / device-preprocessing path against
-its host path.  ALE is absent: tests/fake_ale.py stands in for the emulator."""
+"""The Atari adapter (paac_amd/atari_emulator.py) against captures of the reference's own AtariEmulator class
+(atari_emulator.py:15-118) stepped by the reference's own EmulatorRunner._run (tests/golden/atari_emulator_flow.npz,
+made by tests/golden/make_golden_atari.py), and its raw-screen / device-preprocessing path against its host path and
+against the same captures.  ALE is absent: tests/fake_ale.py stands in for the emulator, here and in the capture."""
 import argparse
+import hashlib
 import os
 import random
 import sys
@@ -12,6 +14,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from fake_ale import FakeALE
 from oracle import preprocess as opre
+from oracle.atari_flow import ReferenceFlow
 
 
 def emu_args(**kw):
@@ -21,84 +24,70 @@ def emu_args(**kw):
     return argparse.Namespace(**d)
 
 
-class ReferenceFlow(object):
-    """atari_emulator.py:60-112 restated step by step on the oracle's FramePool / ObservationPool / max_resize."""
-
-    def __init__(self, actor_id, args, ale=None):
-        self.ale = FakeALE() if ale is None else ale
-        self.ale.setInt(b"random_seed", args.random_seed * (actor_id + 1))
-        self.legal = self.ale.getMinimalActionSet()
-        self.args = args
-        self.lives = self.ale.lives()
-        self.frames = opre.FramePoolOracle()
-        self.obs = opre.ObservationPoolOracle()
-
-    def _screen(self):
-        g = np.zeros((210, 160, 1), dtype=np.uint8)
-        self.ale.getScreenGrayscale(g)
-        return g[..., 0]
-
-    def _repeat(self, a):
-        r = 0
-        for _ in range(2):
-            r += self.ale.act(self.legal[a])
-        for _ in range(2):
-            r += self.ale.act(self.legal[a])
-            self.frames.new_frame(self._screen())
-        return r
-
-    def _terminal(self):
-        if self.args.single_life_episodes:
-            return self.ale.game_over() or self.lives > self.ale.lives()
-        return self.ale.game_over()
-
-    def initial(self):
-        self.ale.reset_game()
-        self.lives = self.ale.lives()
-        if self.args.random_start:
-            for _ in range(random.randint(0, 30)):
-                self.ale.act(self.legal[0])
-        for _ in range(4):
-            self._repeat(0)
-            self.obs.new_observation(self.frames.get_processed_frame())
-        return self.obs.get_pooled_observations()
-
-    def next(self, a):
-        r = self._repeat(a)
-        self.obs.new_observation(self.frames.get_processed_frame())
-        term = self._terminal()
-        self.lives = self.ale.lives()
-        return self.obs.get_pooled_observations(), r, term
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "atari_emulator_flow.npz")
+CASES = [(False, True), (True, False), (True, True)]        # (single_life_episodes, random_start), actors 0 and 2
 
 
-@pytest.mark.parametrize("single_life,random_start", [(False, True), (True, False), (True, True)])
+def golden_case(single_life, random_start, actor):
+    """One capture of the reference's own AtariEmulator + EmulatorRunner._run (tests/golden/make_golden_atari.py)."""
+    z = np.load(GOLDEN)
+    key = "sl%d_rs%d_a%d/" % (single_life, random_start, actor)
+    rec = {k[len(key):]: z[k] for k in z.files if k.startswith(key)}
+    rec["episode_frames"] = int(z["episode_frames"])
+    return rec
+
+
+def sha(o):
+    return hashlib.sha256(np.ascontiguousarray(o).tobytes()).hexdigest()
+
+
+def check_against_capture(rec, observations, rewards, terminals):
+    """observations: the initial one + one per runner step (fresh initial state after a terminal)."""
+    assert np.array_equal(np.asarray(rewards, dtype=np.float32), rec["rewards"])
+    assert np.array_equal(np.asarray(terminals, dtype=np.bool_), rec["terminals"])
+    assert rec["terminals"].sum() >= 2, "the capture must contain resets"
+    assert len(observations) == len(rec["obs_sha256"])
+    for k, o in enumerate(observations):
+        assert o.dtype == np.uint8 and o.shape == (84, 84, 4)
+        assert sha(o) == str(rec["obs_sha256"][k]), "observation %d differs from the reference's" % k
+    for k, full in zip(rec["full_idx"], rec["full_obs"]):
+        assert np.array_equal(observations[int(k)], full)
+
+
+@pytest.mark.parametrize("single_life,random_start", CASES)
+def test_oracle_flow_reproduces_the_reference_capture(single_life, random_start):
+    """oracle/atari_flow.py (the restatement the -m gpu loop test checks against) is pinned to the reference's class."""
+    for actor in (0, 2):
+        rec = golden_case(single_life, random_start, actor)
+        random.seed(int(rec["seed"]))
+        flow = ReferenceFlow(actor, emu_args(single_life_episodes=single_life, random_start=random_start),
+                             FakeALE(episode_frames=rec["episode_frames"]))
+        obs, rewards, terminals = [flow.initial()], [], []
+        for a in rec["actions"]:
+            o, r, t = flow.runner_step(int(a))
+            obs.append(o), rewards.append(r), terminals.append(t)
+        check_against_capture(rec, obs, rewards, terminals)
+
+
+@pytest.mark.parametrize("single_life,random_start", CASES)
 def test_adapter_follows_reference_episode_semantics(single_life, random_start):
+    """The product adapter, driven by the captured actions on the same FakeALE and `random` seed, reproduces what the
+    reference's AtariEmulator + EmulatorRunner produced: every shared observation, reward and terminal flag."""
     from paac_amd.atari_emulator import AtariEmulator
     args = emu_args(single_life_episodes=single_life, random_start=random_start)
     for actor in (0, 2):
-        random.seed(11 + actor)
-        emu = AtariEmulator(actor, args, ale=FakeALE())
-        got = [emu.get_initial_state()]
-        rs = np.random.RandomState(actor)
-        actions = rs.randint(0, 4, 120)
-        trace = []
-        for a in actions:
+        rec = golden_case(single_life, random_start, actor)
+        random.seed(int(rec["seed"]))
+        emu = AtariEmulator(actor, args, ale=FakeALE(episode_frames=rec["episode_frames"]))
+        assert np.array_equal(np.asarray(emu.get_legal_actions()), rec["legal_actions"])
+        obs, rewards, terminals = [emu.get_initial_state()], [], []
+        for a in rec["actions"]:
             o, r, t = emu.next(np.eye(4)[a])
-            trace.append((r, t))
-            got.append(emu.get_initial_state() if t else o)
-        random.seed(11 + actor)
-        ref = ReferenceFlow(actor, args)
-        want = [ref.initial()]
-        for a, (r_got, t_got) in zip(actions, trace):
-            o, r, t = ref.next(a)
-            assert (r, t) == (r_got, t_got)
-            want.append(ref.initial() if t else o)
-        assert sum(t for _, t in trace) >= 2, "the trace must contain resets"
-        for k, (g, w) in enumerate(zip(got, want)):
-            assert g.dtype == np.uint8 and g.shape == (84, 84, 4)
-            assert np.array_equal(g, w), "observation %d differs" % k
+            obs.append(emu.get_initial_state() if t else o)      # emulator_runner.py:24-31
+            rewards.append(r), terminals.append(t)
+        check_against_capture(rec, obs, rewards, terminals)
         assert emu.ale.options[b"repeat_action_probability"] == 0.0 and emu.ale.options[b"frame_skip"] == 1
-        assert emu.ale.options[b"color_averaging"] is False and emu.get_noop() == [1.0, 0.0]
+        assert emu.ale.options[b"color_averaging"] is False and emu.get_noop() == list(rec["noop"]) == [1.0, 0.0]
 
 
 def test_raw_screens_rebuild_the_host_observations():
@@ -139,6 +128,45 @@ def test_runner_protocol_for_raw_screens():
             assert counts[i] == (4 if overs[i] else 1)
             seen_reset |= bool(overs[i])
     assert seen_reset
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("single_life,random_start", CASES)
+def test_device_preprocessing_reproduces_the_reference_capture(single_life, random_start):
+    """Raw screen pairs of the product adapter -> pinned staging -> paac_preprocess_stack (DeviceObservations, the
+    --device_preprocess path) == the observations the reference's AtariEmulator + EmulatorRunner produced, resets
+    included; both actors of a case are stepped as one batch of two environments."""
+    torch = pytest.importorskip("torch")
+    from paac_amd.atari_emulator import AtariEmulator
+    from paac_amd.paac import DeviceObservations
+    args = emu_args(single_life_episodes=single_life, random_start=random_start)
+    recs = [golden_case(single_life, random_start, actor) for actor in (0, 2)]
+    emus, firsts = [], []
+    for actor, rec in zip((0, 2), recs):       # the capture seeded `random` per actor: draw each actor's first reset alone
+        random.seed(int(rec["seed"]))
+        emus.append(AtariEmulator(actor, args, ale=FakeALE(episode_frames=rec["episode_frames"])))
+        firsts.append(emus[-1].initial_raw())
+        rec["rnd"] = random.getstate()
+    dobs = DeviceObservations(2, 4, torch.device("cuda", 0))
+    raw = np.stack(firsts)                                         # [2, 4 slots, 2, 210, 160]
+    obs = [[o] for o in dobs.update(raw, [4, 4]).cpu().numpy()]
+    rewards, terminals = [[], []], [[], []]
+    for k in range(len(recs[0]["actions"])):
+        counts = []
+        for e, (emu, rec) in enumerate(zip(emus, recs)):
+            random.setstate(rec["rnd"])
+            pair, r, t = emu.next_raw(np.eye(4)[rec["actions"][k]])
+            if t:                                                  # emulator_runner.py:24-31: fresh initial state
+                raw[e] = emu.initial_raw()
+            else:
+                raw[e, 0] = pair
+            rec["rnd"] = random.getstate()
+            counts.append(4 if t else 1)
+            rewards[e].append(r), terminals[e].append(t)
+        for e, o in enumerate(dobs.update(raw, counts).cpu().numpy()):
+            obs[e].append(o)
+    for e, rec in enumerate(recs):
+        check_against_capture(rec, obs[e], rewards[e], terminals[e])
 
 
 @pytest.mark.gpu
@@ -183,12 +211,12 @@ def test_device_preprocessing_loop_equals_host_loop():
     for c, (a, b) in enumerate(zip(feeds[False], feeds[True])):
         assert np.array_equal(a["states"], b["states"]), "cycle %d: observations differ" % c
         assert np.array_equal(a["actions"], b["actions"]) and np.array_equal(a["y"], b["y"])
-    # ... and against the ORACLE: the reference's episode flow (atari_emulator.py:60-112, emulator_runner.py:24-31)
-    # restated on the oracle's FramePool / ObservationPool / PIL-nearest LUT, driven by the recorded actions -- every
-    # observation the device-preprocessing loop trained on, bit for bit, resets included
+    # ... and against the ORACLE (oracle/atari_flow.py, pinned to the reference's own AtariEmulator by
+    # test_oracle_flow_reproduces_the_reference_capture), driven by the recorded actions -- every observation the
+    # device-preprocessing loop trained on, bit for bit, resets included
     random.seed(5)
     ref_args = emu_args(random_start=True, single_life_episodes=True)
-    flows = [ReferenceFlow(i, ref_args, ale=FakeALE(episode_frames=110)) for i in range(N)]
+    flows = [ReferenceFlow(i, ref_args, FakeALE(episode_frames=110)) for i in range(N)]
     shared = [f.initial() for f in flows]
     resets = 0
     for c, feed in enumerate(feeds[True]):
