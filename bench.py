@@ -43,8 +43,19 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16; conv1 spends 3 exact bf16 products
 PEAK_HBM_GBS = 8000.0
 
 
+def mfma_ceiling(bodies, mix):
+    """TFLOP/s ceiling (in algorithmic fp32-equivalent FLOPs) of a launch whose contraction bodies `bodies` (FLOPs each) ran
+    the instruction mixes `mix` (MFMA products issued per fp32 multiply, recorded by the library at launch time): 1 = fp32
+    MFMA (157.3 TFLOP/s), 3 / 6 = exact / split bf16 on the dense-bf16 MFMA (2500 / products).  Harmonic over the bodies."""
+    if not bodies or len(mix) != len(bodies) or sum(bodies) <= 0:
+        return None
+    t = sum(f / (PEAK_FP32_MFMA_TFLOPS if p <= 1 else PEAK_BF16_MFMA_TFLOPS / p) for f, p in zip(bodies, mix))
+    return sum(bodies) / t
+
+
 def family_work(name, batch, arch, A, P, raw=False):
-    """Algorithmic work of one launch of a kernel family: (kind, amount) with kind 'flop' or 'byte'."""
+    """Algorithmic work of one launch of a kernel family: (kind, amount) with kind 'flop' or 'byte'; for 'flop' the amount
+    is the list of its contraction bodies' FLOPs in launch order (the library names paired launches for what they ran)."""
     if arch == "NATURE":
         C1, C2, C3, H, FLAT = 32, 64, 64, 512, 3136
         conv3 = 2.0 * batch * 49 * 576 * 64
@@ -54,14 +65,13 @@ def family_work(name, batch, arch, A, P, raw=False):
     conv1 = 2.0 * batch * 400 * 256 * C1
     conv2 = 2.0 * batch * 81 * (16 * C1) * C2
     fc = 2.0 * batch * FLAT * H
-    table = {"conv1_fwd": conv1, "conv1_wgrad": conv1, "conv2_fwd": conv2, "conv2_wgrad": conv2, "conv2_dgrad": conv2,
-             "conv3_fwd": conv3, "conv3_wgrad": conv3, "conv3_dgrad": conv3, "fc_fwd": fc, "fc_wgrad": fc, "fc_dgrad": fc}
-    table["conv_tower"] = conv1 + conv2 + conv3      # the three conv layers in one launch (csrc/tower.h): algorithmic FLOPs
-    if arch == "NATURE" and os.environ.get("PAAC_TOWER", "1") != "0":
-        table["conv3_dgrad"] = conv3 + conv2         # conv3 AND conv2 data gradients in one launch (csrc/dgrad_tower.h)
-        if os.environ.get("PAAC_WGRAD_PAIR", "1") != "0" and 64 < batch <= 512:
-            table["conv2_wgrad"] = conv2 + conv1     # conv2 AND conv1 weight gradients in one launch (dmm_pair_kernel)
-            table["conv3_wgrad"] = conv3 + fc        # fc AND conv3 weight gradients in one launch
+    table = {"conv1_fwd": [conv1], "conv1_wgrad": [conv1], "conv2_fwd": [conv2], "conv2_wgrad": [conv2],
+             "conv2_dgrad": [conv2], "conv3_fwd": [conv3], "conv3_wgrad": [conv3], "conv3_dgrad": [conv3], "fc_fwd": [fc],
+             "fc_wgrad": [fc], "fc_dgrad": [fc],
+             "conv_tower": [conv1, conv2 + conv3],       # the three conv layers in one launch (csrc/tower.h)
+             "dgrad_tower": [conv3 + conv2],             # conv3 AND conv2 data gradients in one launch (csrc/dgrad_tower.h)
+             "fc_conv3_wgrad": [fc, conv3],              # dmm_pair_kernel: what the launcher paired (net_bwd.hip)
+             "conv2_conv1_wgrad": [conv2, conv1]}
     if name in table:
         return "flop", table[name]
     if name == "clip_rmsprop":      # read g (norm) + read g, ms, var + write ms, mom, var (momentum 0: slot not read)
@@ -228,8 +238,8 @@ def main():
                         blocker.fill_((c + r) & 255)
                 ro.run_cycle()
             ro.synchronize()
-            for name, batch, ms in learner.ctx.prof_read():
-                d = per.setdefault((name, batch), [0.0, 0])
+            for name, batch, ms, mix in learner.ctx.prof_read(with_mix=True):
+                d = per.setdefault((name, batch), [0.0, 0, mix])
                 d[0] += ms
                 d[1] += 1
             steps_done += chunk
@@ -240,14 +250,25 @@ def main():
         P = learner.network.layout["total_unpadded"]
         arch = "NIPS" if a.arch == "NIPS" else "NATURE"
         kernels = []
-        for (name, batch), (ms, cnt) in per.items():
+        for (name, batch), (ms, cnt, mix) in per.items():
             kind, amount = family_work(name, batch, arch, A, P, raw=a.raw_frames)
+            bodies = amount if kind == "flop" else None
+            amount = sum(bodies) if bodies else amount
             avg_us = 1000.0 * ms / cnt
             ach = amount / (avg_us * 1e-6) if avg_us > 0 else 0.0
-            kernels.append(dict(kernel=name, batch=batch, launches_per_step=cnt / a.steps, avg_us=round(avg_us, 3),
-                                us_per_step=round(1000.0 * ms / a.steps, 2),
-                                achieved=(round(ach / 1e12, 3) if kind == "flop" else round(ach / 1e9, 1)) if amount > 0 else None,
-                                unit="TFLOP/s" if kind == "flop" else "GB/s"))
+            k = dict(kernel=name, batch=batch, launches_per_step=cnt / a.steps, avg_us=round(avg_us, 3),
+                     us_per_step=round(1000.0 * ms / a.steps, 2),
+                     achieved=(round(ach / 1e12, 3) if kind == "flop" else round(ach / 1e9, 1)) if amount > 0 else None,
+                     unit="TFLOP/s" if kind == "flop" else "GB/s")
+            if k["achieved"] is not None:
+                # the ceiling of what the family ran: its recorded instruction mix on the MFMA, HBM otherwise
+                peak = mfma_ceiling(bodies, mix) if kind == "flop" else PEAK_HBM_GBS
+                if peak:
+                    k["peak"] = round(peak, 1)
+                    k["frac"] = round(k["achieved"] / peak, 4)
+                if kind == "flop":
+                    k["mfma_products_per_multiply"] = list(mix)
+            kernels.append(k)
         kernels.sort(key=lambda k: -k["us_per_step"])
         dom = [k for k in kernels if k["achieved"] is not None][0]
         # HBM-side traffic of the dominant kernel from the committed PMC passes (collected separately, as rocprofv3
@@ -266,22 +287,21 @@ def main():
         except Exception:
             traffic = None
         if dom["unit"] == "TFLOP/s":
+            # frac: against the ceiling of the instruction mix the family ran (cannot exceed 1); frac_fp32_contract: the
+            # same achieved figure against the fp32-MFMA peak SURVEY 8(d) prices the network at (a bf16-split family can
+            # exceed 1 there: it is a different instruction)
             roofline = dict(bound="mfma", kernel="%s[batch=%d]" % (dom["kernel"], dom["batch"]), achieved=dom["achieved"],
-                            peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                            peak=dom.get("peak", PEAK_FP32_MFMA_TFLOPS), unit="TFLOP/s",
+                            frac=dom.get("frac", round(dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)),
+                            frac_fp32_contract=round(dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                            peak_fp32_contract=PEAK_FP32_MFMA_TFLOPS,
+                            mfma_products_per_multiply=dom.get("mfma_products_per_multiply"),
                             avg_launch_us=dom["avg_us"], traffic=traffic)
             if dom["kernel"] == "conv_tower":
-                roofline["peak_as_implemented"] = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
-                roofline["note"] = ("achieved = algorithmic fp32-equivalent FLOP/s of conv1+conv2+conv3 in one launch; as "
-                                    "implemented: bf16 MFMA on exactly split operands (3 products per multiply in conv1, 6 in "
-                                    "conv2/conv3; with 4 regions per sample about 2x of the conv1/conv2 arithmetic is "
-                                    "recomputed); every workgroup streams all 466 KB of pre-split conv weights from L2")
-            if dom["kernel"].startswith("conv1"):
-                # the path computes fp32 results (dtype f32) and is priced against the fp32 MFMA peak; as implemented
-                # conv1 issues three exact bf16 MFMA products per multiply, whose own ceiling is far higher
-                roofline["peak_as_implemented"] = round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)
-                roofline["note"] = ("achieved = fp32-equivalent FLOP/s; conv1 multiplies exact-bf16 pixels with fp32 "
-                                    "weights split exactly into 3 bf16 terms on v_mfma_f32_16x16x32_bf16 (dense bf16 peak "
-                                    "/ 3); at 32 rows the kernel is bound by dispatch + first-load latency, not by MFMA")
+                roofline["note"] = ("achieved = algorithmic fp32-equivalent FLOP/s of conv1+conv2+conv3 in one launch; peak = "
+                                    "dense bf16 MFMA / products per multiply (3 in conv1, 6 in conv2/conv3), harmonic over "
+                                    "the layers' FLOPs; with several regions per sample part of the conv1/conv2 arithmetic "
+                                    "is recomputed and every workgroup streams all 466 KB of pre-split conv weights from L2")
         else:
             roofline = dict(bound="hbm", kernel="%s[batch=%d]" % (dom["kernel"], dom["batch"]), achieved=dom["achieved"],
                             peak=PEAK_HBM_GBS, unit="GB/s", frac=round(dom["achieved"] / PEAK_HBM_GBS, 4),
@@ -293,7 +313,8 @@ def main():
         envs = [env_creator.create_environment(i) for i in range(N)]
         params = onet.init_params(a.arch, A, np.random.RandomState(0), dtype=np.float32)
         res = cpu_learner.run(envs, a.arch, A, T, params, min_seconds=a.cpu_seconds)
-        cpu_baseline = dict(value=round(res["steps_per_s"], 1), unit="env-steps/s", cores=res["cores"], kind="port",
+        cpu_baseline = dict(value=round(res["steps_per_s"], 1), unit="env-steps/s", cores=res["cores"],
+                            threads=res["cores"], host_cores=os.cpu_count(), kind="port",
                             sample="%d cycles of the same workload (%d envs x t_max %d, %s net) in %.1f s, torch-CPU fp32 port "
                                    "of the reference loop; median of %d windows (%s env-steps/s), %d threads fixed after calibration"
                                    % (res["cycles"], N, T, a.arch, res["seconds"], res["windows"],
@@ -321,7 +342,12 @@ def main():
                                      "bf16 MFMA with each fp32 operand split EXACTLY into 3 bf16 terms (u8 pixels are exact "
                                      "in one), fp32 accumulation; of the 9 partial products the 3 below 2^-23 of the leading "
                                      "one are dropped.  The acting fc layer (<= 64 rows) runs on the fp32 MFMA",
-                       "parallelism": "env-sharded dp%d, RCCL sum all-reduce of the flat gradient per update (fc/heads part overlapped with the conv backward)" % world},
+                       "parallelism": "env-sharded dp%d, %s" % (world, (
+                           "no collective (one process)" if world == 1 and not ro.phased else
+                           "ONE RCCL sum all-reduce of the flat gradient per update, after the full backward, on the rollout stream"
+                           if ro.single_exchange else
+                           "RCCL sum all-reduce of the flat gradient per update in two pieces (PAAC_ALLREDUCE=split: the fc/heads "
+                           "tail overlaps the conv backward)"))},
             "finite_params": finite,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_plugin_loop": host_loop, "kernels": kernels,
         }

@@ -292,9 +292,14 @@ int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);
  * paac_prof_read synchronises the recorded events and returns, per launch, its kernel family, the batch it
  * processed and its duration in ms (up to max_events; the internal table holds 8192 launches); returns the
  * number of records written and clears the table.  The entry points that take no ctx (environment step, samplers,
- * n-step returns, preprocessing) are recorded in the table of the ctx profiling was last enabled on. */
-#define PAAC_PROF_FAMILIES 23
+ * n-step returns, preprocessing) are recorded in the table of the ctx profiling was last enabled on.
+ * paac_prof_read_mix (call it BEFORE paac_prof_read, which clears the table; no synchronisation) returns per launch the
+ * instruction mix of its contraction bodies, one byte per body in launch order: MFMA products issued per fp32 multiply
+ * (1 = fp32 MFMA, 3 = exact-bf16 path, 6 = split-bf16 path; 0 = no contraction) -- so that a family is priced against the
+ * ceiling of what it ran. */
+#define PAAC_PROF_FAMILIES 26
 int paac_prof_enable(paac_ctx* ctx, int on);
+int paac_prof_read_mix(paac_ctx* ctx, int32_t* mix_out, int max_events);
 int paac_prof_read(paac_ctx* ctx, int32_t* family_out, int32_t* batch_out, float* ms_out, int max_events);
 const char* paac_prof_name(int family);
 

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "paac_debug_clock": (c_int, [c_void_p, c_void_p]),
     "paac_prof_enable": (c_int, [c_void_p, c_int]),
     "paac_prof_read": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_int]),
+    "paac_prof_read_mix": (c_int, [c_void_p, POINTER(c_int32), c_int]),
     "paac_prof_name": (c_char_p, [c_int]),
 }
 

@@ -169,6 +169,12 @@ class ActorLearner(object):
         if optimizer_checkpoint is not None:
             logging.info('Restoring optimizer variables from previous run')
             self.optimizer_saver.restore(self.session, optimizer_checkpoint)
+            # save_vars writes the network first and the optimizer second, and a torn newest file is skipped on resume:
+            # the two can come from different updates (upstream has the same window, silently)
+            optimizer_step = Saver.step_of(optimizer_checkpoint)
+            if optimizer_step is not None and optimizer_step != int(resumed_step):
+                logging.warning('Optimizer checkpoint is from step %d, network checkpoint from step %d: resuming with '
+                                'weights and RMSProp statistics of different updates', optimizer_step, int(resumed_step))
         if parallel.world_size() > 1:
             step = torch.tensor([int(resumed_step)], dtype=torch.int64, device=self.torch_device)
             for t in (self.network.params, self.rms, self.mom, step):

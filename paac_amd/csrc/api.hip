@@ -9,7 +9,7 @@
 namespace paac {
 
 static thread_local char g_err[512] = "";
-thread_local ProfEvents g_prof = {nullptr, nullptr};
+thread_local ProfEvents g_prof = {nullptr, nullptr, 0, 0};
 paac_ctx* g_prof_ctx = nullptr;
 
 void set_error(const char* fmt, ...) {
@@ -47,7 +47,8 @@ int fc_splits_max();
 static const char* kFamilyNames[PAAC_PROF_FAMILIES] = {
     "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "heads_fwd", "heads_bwd", "fc_wgrad", "fc_dgrad",
     "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "grad_finalize", "clip_rmsprop", "misc",
-    "env_step", "sample_env_step", "sample_mt", "sample_philox", "nstep_returns", "preprocess_stack", "conv_tower"};
+    "env_step", "sample_env_step", "sample_mt", "sample_philox", "nstep_returns", "preprocess_stack", "conv_tower",
+    "fc_conv3_wgrad", "conv2_conv1_wgrad", "dgrad_tower"};
 
 }  // namespace paac
 
@@ -168,6 +169,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   c->ev_stop = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
   c->ev_family = new int[paac_ctx::PROF_MAX_EVENTS];
   c->ev_batch = new int[paac_ctx::PROF_MAX_EVENTS];
+  c->ev_mix = new int[paac_ctx::PROF_MAX_EVENTS];
   c->ev_count = 0;
   c->prof_on = 0;
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
@@ -203,6 +205,7 @@ int paac_destroy(paac_ctx* c) {
   delete[] c->ev_stop;
   delete[] c->ev_family;
   delete[] c->ev_batch;
+  delete[] c->ev_mix;
   delete c;
   return 0;
 }
@@ -468,6 +471,13 @@ int paac_prof_read(paac_ctx* ctx, int32_t* family_out, int32_t* batch_out, float
     }
   }
   ctx->ev_count = 0;
+  return n;
+}
+
+int paac_prof_read_mix(paac_ctx* ctx, int32_t* mix_out, int max_events) {
+  PAAC_REQUIRE(ctx && mix_out, "paac_prof_read_mix: null argument");
+  int n = 0;
+  for (int i = 0; i < ctx->ev_count && n < max_events; ++i) mix_out[n++] = ctx->ev_mix[i];
   return n;
 }
 

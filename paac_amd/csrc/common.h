@@ -50,9 +50,11 @@ enum Family {
   F_HEADS_BWD, F_FC_WGRAD, F_FC_DGRAD, F_CONV3_WGRAD, F_CONV3_DGRAD, F_CONV2_WGRAD, F_CONV2_DGRAD, F_CONV1_WGRAD,
   F_GRAD_FINALIZE, F_CLIP_RMSPROP, F_MISC,
   // the kernels around the network (entry points without a ctx: timed through the ctx profiling was enabled on)
-  F_ENV_STEP, F_SAMPLE_ENV_STEP, F_SAMPLE_MT, F_SAMPLE_PHILOX, F_NSTEP_RETURNS, F_PREPROCESS_STACK, F_CONV_TOWER
+  F_ENV_STEP, F_SAMPLE_ENV_STEP, F_SAMPLE_MT, F_SAMPLE_PHILOX, F_NSTEP_RETURNS, F_PREPROCESS_STACK, F_CONV_TOWER,
+  // two contractions in one launch (dmm_pair_kernel) and the conv3 + conv2 data-gradient tower: named for what ran
+  F_FC_CONV3_WGRAD, F_CONV2_CONV1_WGRAD, F_DGRAD_TOWER
 };
-static_assert(F_CONV_TOWER + 1 == PAAC_PROF_FAMILIES, "family count");
+static_assert(F_DGRAD_TOWER + 1 == PAAC_PROF_FAMILIES, "family count");
 
 }  // namespace paac
 
@@ -133,6 +135,7 @@ struct paac_ctx {
   hipEvent_t* ev_stop;
   int* ev_family;
   int* ev_batch;
+  int* ev_mix;     // bf16 products per fp32 multiply of the launch's contraction bodies, one byte each (prof_mix)
   int ev_count;
 };
 
@@ -144,6 +147,7 @@ namespace paac {
 // (first_only / last_only) puts the start on the first and the stop on the last.
 struct ProfEvents {
   hipEvent_t start, stop;
+  int mix, nmix;
 };
 extern thread_local ProfEvents g_prof;
 extern paac_ctx* g_prof_ctx;   // the ctx paac_prof_enable(ctx, 1) was last called on (nullptr: none)
@@ -161,10 +165,20 @@ struct ProfScope {
     }
   }
   ~ProfScope() {
+    if (idx >= 0) ctx->ev_mix[idx] = g_prof.mix;
     g_prof.start = nullptr;
     g_prof.stop = nullptr;
+    g_prof.mix = 0;
+    g_prof.nmix = 0;
   }
 };
+
+// Instruction mix of a contraction body launched inside the current ProfScope: MFMA products issued per fp32 multiply --
+// 1 = fp32 MFMA, 3 = exact-bf16 path (u8 operand x fp32 split into 3 bf16 terms), 6 = split-bf16 path.  bench.py prices
+// the family against the ceiling of what it actually ran.  Up to four bodies per launch, in launch order.
+inline void prof_mix(int products) {
+  if (g_prof.start && g_prof.nmix < 4) g_prof.mix |= (products & 255) << (8 * g_prof.nmix++);
+}
 
 enum { PROF_WHOLE = 0, PROF_FIRST = 1, PROF_LAST = 2, PROF_NONE = 3 };
 template <class K, class... Args>

@@ -204,6 +204,7 @@ struct Dmm {
   using G = G_;
   static constexpr int EPI = EPI_;
   static constexpr int GS = XB ? 2 : 1;          // 16-wide K groups per pipeline stage
+  static constexpr int PRODUCTS = XB == 0 ? 1 : XB == 1 ? 3 : 6;   // MFMA products per fp32 multiply (prof_mix)
   static constexpr int KSTAGE = 16 * GS;
   static_assert(XB != 1 || (U8 && BP == FRAG_MN), "exact-bf16 path: u8 A operand, fp32 FRAG_MN B operand");
   // conv1 forward on the exact path: a K stage is exactly one patch row (8 pixels x 4 channels = 32 contiguous
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(D::THREADS) void dmm_kernel(const GemmArgs p) {
 // Fills the launch geometry of `a` for body D; returns the number of workgroups.
 template <class D>
 inline long prepare_dmm(GemmArgs& a, int zdim, int ksplit_z, int xcd_dim) {
+  prof_mix(D::PRODUCTS);
   const int ngroups = (a.K + D::KSTAGE - 1) / D::KSTAGE;
   const int parts = D::WAVES_K * ((D::EPI == EPI_SLAB) ? ksplit_z : 1);
   a.groups_per_part = (ngroups + parts - 1) / parts;

@@ -412,14 +412,22 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
     mw.exits[wid] = (unsigned short)o;
   }
   MISC_STAMP(9);
-  // hand-off: the barrier makes the workgroup's records visible to its thread 0, whose device-scope release (fence, then the
-  // ticket) publishes them -- one fence per workgroup, not one per thread; the same on the acquiring side
+  // hand-off: every storing thread first drains its own stores to the L2 (workgroup-scope release: s_waitcnt vmcnt(0), no
+  // cache maintenance) -- the barrier alone does not wait for another wave's stores in flight --, then thread 0's
+  // device-scope release (L2 write-back, then the ticket) publishes the whole workgroup's records: one write-back per
+  // workgroup, not one per thread; the same on the acquiring side.  The workgroup that takes the last ticket puts the
+  // counter back to 0 (every ticket of this launch has been taken; the next launch is stream-ordered behind this one), so
+  // the counter never leaves [0, W] and cannot wrap.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   __shared__ int last_s;
   if (tid == 0) {
     __threadfence();
-    last_s = (atomicAdd(mw.counter, 1u) % (unsigned int)mw.W) == (unsigned int)(mw.W - 1);
-    if (last_s) __threadfence();
+    last_s = atomicAdd(mw.counter, 1u) == (unsigned int)(mw.W - 1);
+    if (last_s) {
+      __threadfence();
+      __hip_atomic_store(mw.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   if (!last_s) return false;

@@ -288,10 +288,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       PairArgs pa;
       pa.g0 = held_gw;
       pa.g1 = gw;
+      ProfScope ps(ctx, F_FC_CONV3_WGRAD, batch, s);
       pa.count0 = (int)prepare_dmm<DF>(pa.g0, held_ks, held_ks, held_xcd);
       const int n1 = (int)prepare_dmm<D3>(pa.g1, k3, k3, x3);
       pa.first1 = (pa.count0 + 7) / 8 * 8;
-      ProfScope ps(ctx, F_CONV3_WGRAD, batch, s);
       launch_k(dmm_pair_kernel<DF, D3>, dim3((unsigned)(pa.first1 + n1)), dim3(128), s, PROF_WHOLE, pa);
       splits = k3;
     } else {
@@ -300,7 +300,8 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     }
     if (ctx->tower_on) {
       // conv3 AND conv2 data gradients in one launch (dgrad_tower.h): da2 -> dact[1], da1 -> dact[0]
-      ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
+      ProfScope ps(ctx, F_DGRAD_TOWER, batch, s);
+      prof_mix(6);     // conv3 and conv2 data gradients, both on the split-bf16 path
       DgradTowerArgs da;
       da.da3 = ctx->dact[2];
       da.act2 = W.act[1];
@@ -363,11 +364,11 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
         PairArgs pa;
         pa.g0 = gw;
         pa.g1 = g1;
-        pa.count0 = (int)prepare_dmm<D2>(pa.g0, k2, k2, x2);
-        const int n1 = (int)prepare_dmm<D1>(pa.g1, k1, k1, x1);
-        pa.first1 = (pa.count0 + 7) / 8 * 8;
         {
-          ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
+          ProfScope ps(ctx, F_CONV2_CONV1_WGRAD, batch, s);
+          pa.count0 = (int)prepare_dmm<D2>(pa.g0, k2, k2, x2);
+          const int n1 = (int)prepare_dmm<D1>(pa.g1, k1, k1, x1);
+          pa.first1 = (pa.count0 + 7) / 8 * 8;
           launch_k(dmm_pair_kernel<D2, D1>, dim3((unsigned)(pa.first1 + n1)), dim3(256), s, PROF_WHOLE, pa);
         }
         splits = k2;

@@ -192,6 +192,8 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   if (!ctx->managed_weights && (tower || batch <= kFcHeadsMaxRows)) launch_pack_weights(ctx, params, s);
   if (tower) {
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
+    prof_mix(3);       // conv1: u8 pixels x weights split into 3 bf16 terms
+    prof_mix(6);       // conv2, conv3: six-product split-bf16
     launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s);
   }
   if (!tower) {
@@ -223,6 +225,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     const bool keep_h = keep_acts;
     {
       ProfScope ps(ctx, F_FC_FWD, batch, s);
+      prof_mix(1);     // fp32 MFMA
       constexpr int NW = (NT::FLAT / 16) % 7 == 0 ? 7 : 9;      // waves per workgroup: divides the K groups evenly
       if (packed3)
         launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, true>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,

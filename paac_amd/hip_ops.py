@@ -259,15 +259,23 @@ class Context(object):
     def prof_enable(self, on=True):
         _lib.check(self.lib.paac_prof_enable(self.handle, 1 if on else 0), "paac_prof_enable")
 
-    def prof_read(self):
-        """-> list of (family name, batch, milliseconds), one per kernel-family launch since the last read."""
+    def prof_read(self, with_mix=False):
+        """-> list of (family name, batch, milliseconds), one per kernel-family launch since the last read; with_mix adds
+        the launch's instruction mix as a tuple of MFMA products per fp32 multiply, one entry per contraction body
+        (include/paac_hip.h: paac_prof_read_mix)."""
         cap = 8192
         fam = (ctypes.c_int32 * cap)()
         bat = (ctypes.c_int32 * cap)()
         ms = (ctypes.c_float * cap)()
+        mix = (ctypes.c_int32 * cap)()
+        if with_mix:
+            _lib.check(self.lib.paac_prof_read_mix(self.handle, mix, cap), "paac_prof_read_mix")
         n = self.lib.paac_prof_read(self.handle, fam, bat, ms, cap)
         _lib.check(n, "paac_prof_read")
-        return [(self.lib.paac_prof_name(fam[i]).decode(), int(bat[i]), float(ms[i])) for i in range(n)]
+        out = [(self.lib.paac_prof_name(fam[i]).decode(), int(bat[i]), float(ms[i])) for i in range(n)]
+        if with_mix:
+            out = [o + (tuple(b for b in ((mix[i] >> (8 * k)) & 255 for k in range(4)) if b),) for i, o in enumerate(out)]
+        return out
 
 
 # -- context-free entry points -------------------------------------------------------------------

@@ -490,6 +490,9 @@ class PAACLearner(ActorLearner):
         start_time = time.time()
         self.last_feed = None
         metrics = self._open_metrics()
+        # data parallel: global_step counts the environment steps of ALL ranks (paac.py:127 counts every environment of
+        # the one learner), like the device loop -- lr anneals and max_global_steps ends on the global count
+        world = self._world()
 
         while self.global_step < self.max_global_steps and not parallel.any_rank(self.stop_requested, dev):
             loop_start_time = time.time()
@@ -508,7 +511,7 @@ class PAACLearner(ActorLearner):
                     total_episode_rewards[e] += actual_reward
                     rewards[t, e] = self.rescale_reward(actual_reward)
                     emulator_steps[e] += 1
-                    self.global_step += 1
+                    self.global_step += world
                     if episode_over:
                         total_rewards.append(total_episode_rewards[e])
                         if metrics is not None:                      # paac.py:130-135
@@ -541,11 +544,12 @@ class PAACLearner(ActorLearner):
                 curr_time = time.time()
                 last_ten = 0.0 if len(total_rewards) < 1 else np.mean(total_rewards[-10:])
                 logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), last 10 rewards avg {}"
-                             .format(self.global_step, T * N / (curr_time - loop_start_time),
+                             .format(self.global_step, T * N * world / (curr_time - loop_start_time),
                                      (self.global_step - global_step_start) / (curr_time - start_time), last_ten))
-                self._progress_record(T * N / (curr_time - loop_start_time),
+                self._progress_record(T * N * world / (curr_time - loop_start_time),
                                       (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
             self.save_vars()
+        logging.debug("Host-plugin loop: %d update cycles, global step %d", counter, self.global_step)
         np.random.set_state(hip_ops.mt_state_to_numpy(mt_state))
 
     def _sync_device(self):

@@ -63,6 +63,14 @@ class Saver(object):
         return sorted(glob.glob(os.path.join(folder, "-*.npz")), key=_step_of)
 
     @staticmethod
+    def step_of(path):
+        """Global step a checkpoint file was saved at (the suffix after the last '-', networks.py:134), None if unparsable."""
+        try:
+            return _step_of(path)
+        except ValueError:
+            return None
+
+    @staticmethod
     def latest_checkpoint(folder):
         for path in reversed(Saver.checkpoints(folder)):
             if Saver._readable(path):

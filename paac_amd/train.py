@@ -107,6 +107,12 @@ def _stop(learner, owner_pid, signum, frame):
         logging.info('Signal %s detected, stopping at the next cycle boundary.', signum)
         learner.stop_requested = True
         return
+    if parallel.world_size() > 1:
+        # data parallel: cleanup() is collective (the checkpoint barrier, the pending optimizer step's graph) and only THIS
+        # rank was signalled twice -- running it here would hang this rank in the barrier and leave its peers one
+        # collective out of step.  The first signal's agreed stop is the clean way out; a second one just leaves.
+        logging.info('Signal %s detected again on a data-parallel rank: exiting without the collective cleanup.', signum)
+        os._exit(1)
     logging.info('Signal %s detected again, cleaning up now.', signum)
     learner.cleanup()
     logging.info('Cleanup completed, shutting down...')

@@ -177,3 +177,28 @@ def test_train_module_under_torchrun_two_ranks():
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     assert "Starting training at Step %d" % steps in res.stdout
     assert sorted(os.listdir(os.path.join(folder, "checkpoints"))) == sorted(["-%d.npz" % steps, "-%d.npz" % (steps + 160)])
+
+
+def test_host_plugin_loop_counts_global_steps_over_all_ranks():
+    """`--host_environments true` under torchrun with two ranks: the host-plugin loop (PAACLearner._train_host) advances
+    global_step by the environments of ALL ranks per step, like the device loop (paac.py:127 counts every environment of
+    the one learner) -- it stops at max_global_steps on the global count (3 cycles here, not 6) and anneals lr on it."""
+    import json
+    import subprocess
+    folder = tempfile.mkdtemp(prefix="paac_dp_host_")
+    env = dict(os.environ, PAAC_DIST_BACKEND="gloo", PAAC_DIST_SINGLE_DEVICE="1")
+    G, N, T, cycles = 2, 4, 5, 3
+    steps = G * N * T * cycles
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(G), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "-m", "paac_amd.train", "-g", "breakout", "--arch", "NIPS",
+           "-ec", str(N), "-ew", "2", "--host_environments", "true", "--max_global_steps", str(steps),
+           "-lra", str(4 * steps), "-df", folder]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert os.listdir(os.path.join(folder, "checkpoints")) == ["-%d.npz" % steps]
+    recs = [json.loads(l) for l in open(os.path.join(folder, "metrics.jsonl"))]
+    assert all(r["global_step"] <= steps for r in recs if "global_step" in r)
+    log = res.stdout + res.stderr
+    assert log.count("Starting training (2 data-parallel ranks)") == 2
+    # both ranks ran `cycles` updates (counting local environments only they would have run G times as many)
+    assert log.count("Host-plugin loop: %d update cycles, global step %d" % (cycles, steps)) == 2, log[-3000:]

@@ -362,7 +362,51 @@ def test_fused_sampler_env_step_equals_separate_calls(N, A, multi):
         assert torch.equal(a["s1"], a["s2"])
         want = osamp.sample_numpy_reference(p, ref_rs)
         assert np.array_equal(a["act"].cpu().numpy(), np.asarray(want, dtype=np.int32))
+        if multi:       # the workgroup that took the last ticket put the ticket counter back: it never leaves [0, W]
+            assert int(walk[:4].view(torch.int32).item()) == 0
         for d in (a, b):
             hip_ops.counter_add(d["tick"], 1)
             d["s0"], d["s1"] = d["s1"], d["s0"]
     assert hip_ops.mt_state_to_numpy(a["mt"])[2] == ref_rs.get_state()[2]
+
+
+@pytest.mark.parametrize("N,A", [(256, 4), (128, 18), (96, 6)])
+def test_multi_sampler_exact_zero_fallback(N, A):
+    """Multi-workgroup sampler: a step in which some float32(p - epsneg) is EXACTLY zero (p == 2^-24; numpy draws nothing
+    for that category) takes the serial path in workgroup 0 alone -- the other sampler workgroups leave without a ticket --
+    and the steps around it take the spread walks on the same walk scratch: actions and stream position are numpy's in
+    all of them, and the ticket counter is 0 after every launch."""
+    from paac_amd import hip_ops
+    from paac_amd.synthetic import terminal_threshold
+    env_seed, off, thr = 4, 0, terminal_threshold(0.2)
+    gen = np.random.RandomState(5 * N + A)
+    ref_rs = np.random.RandomState(13)
+    mt = hip_ops.mt_state_from_numpy(np.random.RandomState(13).get_state(), "cuda")
+    s = [torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    hip_ops.synth_reset(env_seed, off, s[0], None)
+    act = torch.zeros(N, dtype=torch.int32, device="cuda")
+    rew, msk, ep_r = (torch.zeros(N, device="cuda") for _ in range(3))
+    ep_l = torch.zeros(N, dtype=torch.int32, device="cuda")
+    tick = torch.zeros(1, dtype=torch.int64, device="cuda")
+    walk = hip_ops.walk_scratch(N, A, "cuda")
+    eps = np.float32(2.0 ** -24)
+    for step, zeros in enumerate([False, True, False, True, True, False]):
+        logits = gen.randn(N, A) * 1.5
+        p = np.exp(logits - logits.max(1, keepdims=True))
+        p = np.maximum(p / p.sum(1, keepdims=True), 1e-6).astype(np.float32)
+        p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        if zeros:
+            for e in gen.choice(N, 5, replace=False):
+                j = gen.randint(0, A - 1)
+                p[e, A - 1] += p[e, j] - eps          # keep the row sum; the last category is never drawn for
+                p[e, j] = eps
+            assert ((p[:, :A - 1] - eps) == 0).sum() == 5
+        hip_ops.sample_mt_synth_step(dev(p), mt, act, env_seed, off, thr, tick, 0, s[0], s[1], rew, msk, ep_r, ep_l, None,
+                                     walk_scratch=walk)
+        torch.cuda.synchronize()
+        want = osamp.sample_numpy_reference(p, ref_rs)
+        assert np.array_equal(act.cpu().numpy(), np.asarray(want, dtype=np.int32)), "step %d" % step
+        assert hip_ops.mt_state_to_numpy(mt)[2] == ref_rs.get_state()[2], "step %d: stream position" % step
+        assert int(walk[:4].view(torch.int32).item()) == 0
+        hip_ops.counter_add(tick, 1)
+        s.reverse()
