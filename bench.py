@@ -138,6 +138,12 @@ def main():
                     help="also time the host-plugin loop (PCIe-inclusive) on the same workload; reported beside value")
     a = ap.parse_args()
 
+    # stdout carries ONE JSON line: whatever libraries print on the way (RCCL 2.26 writes a version banner to stdout when
+    # its communicator comes up) goes to stderr -- file descriptor 1 points at stderr until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -344,14 +350,21 @@ def main():
                                      "one are dropped.  The acting fc layer (<= 64 rows) runs on the fp32 MFMA",
                        "parallelism": "env-sharded dp%d, %s" % (world, (
                            "no collective (one process)" if world == 1 and not ro.phased else
-                           "ONE RCCL sum all-reduce of the flat gradient per update, after the full backward, on the rollout stream"
-                           if ro.single_exchange else
+                           "ONE RCCL sum all-reduce of the flat gradient per update, after the full backward, captured into the "
+                           "cycle's hipGraph" if ro.graph_exchange else
+                           "ONE RCCL sum all-reduce of the flat gradient per update, after the full backward, issued eagerly on "
+                           "the rollout stream" if ro.single_exchange else
                            "RCCL sum all-reduce of the flat gradient per update in two pieces (PAAC_ALLREDUCE=split: the fc/heads "
                            "tail overlaps the conv backward)"))},
             "finite_params": finite,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_plugin_loop": host_loop, "kernels": kernels,
         }
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)           # C stdio buffers of the libraries, while fd 1 is still stderr
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ro.close()
     if dist is not None:
         dist.barrier()

@@ -72,14 +72,20 @@ class DeviceRollout(object):
         self.graph_multi = None                        # MULTI consecutive cycles (parity 0 first) in one launch
         self.graph_ua = [None, None]                   # data parallel: update of the previous cycle + graph_a
         self.pending_update = False
-        # data parallel: the cycle is cut at the gradient exchange (graphs around it, collectives between them)
+        # data parallel: the cycle contains the gradient exchange
         self.phased = parallel.collectives_active()
-        # default: ONE all-reduce of the whole flat gradient after the full backward, launched on the rollout stream -- one
-        # graph + one collective per cycle (measured with a one-rank RCCL group: +15 us per cycle over the plain replay).
-        # PAAC_ALLREDUCE=split: the fc/heads tail (95 % of the bytes) goes out on the collective's stream while the conv
-        # backward still computes (+61 us per cycle of extra graph launch and cross-stream waits before any wire time: pays
-        # only when the large all-reduce takes longer than about 120 us)
-        self.single_exchange = os.environ.get("PAAC_ALLREDUCE", "single") != "split"
+        # PAAC_ALLREDUCE = graph (default): ONE all-reduce of the whole flat gradient after the full backward, CAPTURED into
+        #   the cycle's hipGraph between the backward and the optimizer step -- the data-parallel cycle is replayed exactly
+        #   like the single-process one (MULTI cycles per graph launch, nothing issued eagerly); if the collective cannot be
+        #   captured (backend gloo, or the capture raises) the loop falls back to `single`.
+        # single: the same all-reduce issued eagerly on the rollout stream between two graph launches per cycle (measured
+        #   with a one-rank RCCL group: +15 us per cycle over the plain replay).
+        # split: the fc/heads tail (95 % of the bytes) goes out on the collective's stream while the conv backward still
+        #   computes (+61 us per cycle of extra graph launch and cross-stream waits before any wire time: pays only when
+        #   the large all-reduce takes longer than about 120 us)
+        mode = os.environ.get("PAAC_ALLREDUCE", "graph")
+        self.single_exchange = mode != "split"
+        self.graph_exchange = self.phased and mode == "graph" and use_graph and parallel.backend() == "nccl"
         self.side_group = parallel.side_group() if (self.phased and not self.single_exchange) else None    # collective call
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
@@ -182,8 +188,25 @@ class DeviceRollout(object):
         def cycle(parity, with_update):
             self._rollout_and_backward(parity)
             if with_update:
+                if self.graph_exchange:
+                    self._exchange(None)          # recorded into the graph like the kernels around it
                 self._update()
 
+        if self.graph_exchange:
+            # the communicator must exist before a capture can record its collective: one eager all-reduce of a scratch
+            # word first; a capture that raises leaves the eager form in charge
+            try:
+                parallel.allreduce_sum_(torch.zeros(1, dtype=torch.float32, device=self.L.torch_device))
+                torch.cuda.synchronize(self.L.torch_device)
+                with torch.cuda.stream(self.stream):
+                    for parity in (0, 1):
+                        self.graph_a[parity] = captured(lambda: cycle(parity, True))
+                    self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
+                return
+            except Exception as exc:      # noqa: BLE001 -- whatever the runtime / RCCL raised: keep training, eagerly
+                logging.warning("gradient all-reduce could not be captured into the cycle graph (%s): issuing it eagerly", exc)
+                self.close()
+                self.graph_exchange = False
         with torch.cuda.stream(self.stream):
             for parity in (0, 1):
                 self.graph_a[parity] = captured(lambda: cycle(parity, not self.phased))
@@ -206,7 +229,7 @@ class DeviceRollout(object):
         between two graph launches on the GPU (about 8 us) is paid once per MULTI cycles instead of every cycle."""
         count = int(count)
         while count > 0:
-            if self.use_graph and not self.phased and self.parity == 0 and count >= self.MULTI:
+            if self.use_graph and (not self.phased or self.graph_exchange) and self.parity == 0 and count >= self.MULTI:
                 with torch.cuda.stream(self.stream):
                     if self.graph_a[0] is None:
                         self.capture()
@@ -221,7 +244,7 @@ class DeviceRollout(object):
             if self.use_graph:
                 if self.graph_a[0] is None:
                     self.capture()
-                if self.phased:
+                if self.phased and not self.graph_exchange:
                     (self.graph_ua if self.pending_update else self.graph_a)[self.parity].launch()
                     self._exchange(None if self.single_exchange else self.graph_conv[self.parity].launch)
                     self.pending_update = True

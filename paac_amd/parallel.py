@@ -80,6 +80,11 @@ def any_rank(flag, device):
     return bool(int(t.item()))
 
 
+def backend():
+    """Backend of the default process group ("nccl" = RCCL, "gloo"), None without a group."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

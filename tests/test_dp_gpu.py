@@ -116,9 +116,9 @@ args.emulator_counts, args.max_local_steps, args.emulator_workers = 8, 5, 0
 args.max_global_steps = 1 << 40
 args.synthetic_terminal_p = 0.1
 out = {}
-for mode in ("plain", "split", "single"):
+for mode in ("plain", "split", "single", "graph"):
     os.environ["PAAC_FORCE_COLLECTIVES"] = "0" if mode == "plain" else "1"
-    os.environ["PAAC_ALLREDUCE"] = "single" if mode == "single" else "split"
+    os.environ["PAAC_ALLREDUCE"] = mode if mode != "plain" else "single"
     args.debugging_folder = tempfile.mkdtemp(prefix="paac_rccl_")
     nc, ec = train.get_network_and_environment_creator(args)
     L = PAACLearner(nc, ec, args)
@@ -129,10 +129,12 @@ for mode in ("plain", "split", "single"):
     ro.run_cycles(7)
     ro.synchronize()
     out[mode] = (L.network.params.cpu().numpy().copy(), ro.actions.cpu().numpy().copy(), int(ro.global_step_dev.item()))
-    assert (ro.graph_ua[0] is not None) == (mode != "plain")
+    assert ro.graph_exchange == (mode == "graph")
+    assert (ro.graph_ua[0] is not None) == (mode in ("split", "single"))
     assert (ro.graph_conv[0] is not None) == (mode == "split")
+    assert (ro.graph_multi is not None) == (mode in ("plain", "graph"))      # MULTI cycles per launch survive the exchange
     ro.close()
-for mode in ("split", "single"):
+for mode in ("split", "single", "graph"):
     assert np.array_equal(out[mode][0], out["plain"][0]), mode + ": weights differ from the unphased run"
     assert np.array_equal(out[mode][1], out["plain"][1]) and out[mode][2] == out["plain"][2]
 parallel.shutdown()
@@ -141,10 +143,10 @@ print("RCCL_SMOKE_OK")
 
 
 def test_phased_exchange_runs_under_rccl_world_of_one():
-    """The data-parallel cycle -- graph_a / graph_conv / graph_ua around stream-ordered RCCL all-reduces
-    (DeviceRollout._exchange), both exchange modes -- executed under backend "nccl" on this one GPU (a world of one
-    with the collectives forced on): the all-reduce of one rank is the identity, so the weights after 7 cycles must
-    equal the plain single-process replay bit for bit."""
+    """The data-parallel cycle -- the all-reduce captured INTO the cycle graph (the default), and graph_a / graph_conv /
+    graph_ua around stream-ordered eager RCCL all-reduces (DeviceRollout._exchange, both eager forms) -- executed under
+    backend "nccl" on this one GPU (a world of one with the collectives forced on): the all-reduce of one rank is the
+    identity, so the weights after 7 cycles must equal the plain single-process replay bit for bit."""
     import subprocess
     env = dict(os.environ, PAAC_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()))
