@@ -493,8 +493,8 @@ class PAACLearner(ActorLearner):
             pinned = hip_ops.pin_host_array(host_states)
             current_states = lambda: host_states
 
-        emulator_steps = [0] * N
-        total_episode_rewards = N * [0]
+        emulator_steps = np.zeros(N, dtype=np.int64)
+        total_episode_rewards = np.zeros(N, dtype=np.float64)
         d_states = torch.zeros((T, N, 84, 84, 4), dtype=torch.uint8, device=dev)
         d_cur = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device=dev)
         d_actions = torch.zeros((T, N), dtype=torch.int32, device=dev)
@@ -509,6 +509,11 @@ class PAACLearner(ActorLearner):
         mt_scratch = hip_ops.sample_mt_scratch(N, A, dev)
         rewards = np.zeros((T, N), dtype=np.float32)
         masks = np.zeros((T, N), dtype=np.float32)
+        # the sampled action indices come back through a page-locked buffer: an asynchronous copy + an event instead of a
+        # synchronising .cpu(), so the host does the previous step's bookkeeping while the GPU runs this step's forward
+        h_actions = torch.zeros((N,), dtype=torch.int32).pin_memory()
+        actions_ready = torch.cuda.Event()
+        env_index = np.arange(N)
         params = self.network.params
         start_time = time.time()
         self.last_feed = None
@@ -517,31 +522,43 @@ class PAACLearner(ActorLearner):
         # the one learner), like the device loop -- lr anneals and max_global_steps ends on the global count
         world = self._world()
 
+        def bookkeeping(t, step_rewards, step_overs):
+            """paac.py:119-138 for one step, vectorised over the environments that did not end an episode; the finished
+            ones are visited in index order with the global_step the reference's per-environment loop would show them."""
+            masks[t] = 1.0 - step_overs
+            total_episode_rewards[:] += step_rewards
+            rewards[t] = np.clip(step_rewards, -1.0, 1.0)          # rescale_reward, actor_learner.py:95-101
+            emulator_steps[:] += 1
+            before = self.global_step
+            self.global_step += N * world
+            for e in np.nonzero(step_overs)[0]:
+                total_rewards.append(total_episode_rewards[e])
+                if metrics is not None:                      # paac.py:130-135
+                    metrics.write("episode", global_step=int(before + (e + 1) * world),
+                                  reward=float(total_episode_rewards[e]), length=int(emulator_steps[e]))
+                total_episode_rewards[e] = 0
+                emulator_steps[e] = 0
+
         while self.global_step < self.max_global_steps and not parallel.any_rank(self.stop_requested, dev):
             loop_start_time = time.time()
+            pending = None
             for t in range(T):
                 d_states[t].copy_(current_states(), non_blocking=True)
                 self.ctx.forward(params, d_states[t], probs=d_probs, values=d_values[t])
                 hip_ops.sample_mt(d_probs, mt_state, mt_scratch, d_actions[t])
-                idx = d_actions[t].cpu().numpy()
-                shared_actions[...] = np.eye(A, dtype=np.float32)[idx]
+                h_actions.copy_(d_actions[t], non_blocking=True)
+                actions_ready.record()
+                if pending is not None:            # the previous step's records, while the GPU is busy with this step
+                    bookkeeping(*pending)
+                actions_ready.synchronize()
+                shared_actions[...] = 0.0          # one-hot rows (the convention of runners.py: workers take the argmax)
+                shared_actions[env_index, h_actions.numpy()] = 1.0
                 self.runners.update_environments()
                 self.runners.wait_updated()
                 if raw_mode:
                     observations.update(shared_raw, shared_counts)
-                masks[t] = 1.0 - shared_episode_over.astype(np.float32)
-                for e, (actual_reward, episode_over) in enumerate(zip(shared_rewards, shared_episode_over)):
-                    total_episode_rewards[e] += actual_reward
-                    rewards[t, e] = self.rescale_reward(actual_reward)
-                    emulator_steps[e] += 1
-                    self.global_step += world
-                    if episode_over:
-                        total_rewards.append(total_episode_rewards[e])
-                        if metrics is not None:                      # paac.py:130-135
-                            metrics.write("episode", global_step=int(self.global_step),
-                                          reward=float(total_episode_rewards[e]), length=int(emulator_steps[e]))
-                        total_episode_rewards[e] = 0
-                        emulator_steps[e] = 0
+                pending = (t, shared_rewards.astype(np.float32), shared_episode_over.astype(np.float32))
+            bookkeeping(*pending)
             d_cur.copy_(current_states())
             self.ctx.forward(params, d_cur, values=d_vboot)
             d_rewards.copy_(torch.from_numpy(rewards))

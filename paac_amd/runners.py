@@ -7,7 +7,10 @@ get_shared_variables):
                        (states u8 [N,84,84,4], rewards f32 [N], episode_over f32 [N], actions f32 [N,A]);
                        envs are stepped in the calling process (workers=0) or in `workers` forked
                        processes over shared memory, auto-reset on terminal exactly like
-                       emulator_runner.py:24-31.
+                       emulator_runner.py:24-31.  The "go" token and the completion barrier are POSIX
+                       semaphores (one per worker + one shared) instead of the reference's pickling
+                       multiprocessing.Queue pairs (runners.py:14-15,44-50): the round trip of a step over 8
+                       workers costs about 30 us instead of a millisecond or more.
   * device batching -- environments that have a device twin (EnvironmentCreator.device_env_spec) never
                        touch the host: one paac_synth_step launch per time step (see paac.DeviceRollout).
 """
@@ -53,18 +56,21 @@ def step_emulators_raw(emulators, variables):
 class EmulatorRunner(mp.Process):
     step = staticmethod(step_emulators)
 
-    def __init__(self, id, emulators, variables, queue, barrier):
+    def __init__(self, id, emulators, variables, queue, barrier, stop_flag=None):
+        """queue: this worker's "go" semaphore; barrier: the completion semaphore all workers share; stop_flag: shared
+        int, non-zero = leave at the next token (the reference sends None through the queue, emulator_runner.py:21-23)."""
         super(EmulatorRunner, self).__init__()
         self.id, self.emulators, self.variables, self.queue, self.barrier = id, emulators, variables, queue, barrier
+        self.stop_flag = stop_flag
         self.daemon = True
 
     def run(self):
         while True:
-            instruction = self.queue.get()
-            if instruction is None:
+            self.queue.acquire()
+            if self.stop_flag is not None and self.stop_flag.value:
                 break
             self.step(self.emulators, self.variables)
-            self.barrier.put(True)
+            self.barrier.release()
 
 
 class RawEmulatorRunner(EmulatorRunner):
@@ -81,13 +87,14 @@ class Runners(object):
         if self.workers > 0:
             if len(self.emulators) % self.workers != 0:
                 raise ValueError("emulator_counts must be divisible by emulator_workers (runners.py:17-18)")
-            self.queues = [mp.Queue() for _ in range(self.workers)]
-            self.barrier = mp.Queue()
+            self.queues = [mp.Semaphore(0) for _ in range(self.workers)]
+            self.barrier = mp.Semaphore(0)
+            self.stop_flag = mp.RawValue("i", 0)
             per = len(self.emulators) // self.workers
             for w in range(self.workers):
                 sl = slice(w * per, (w + 1) * per)
                 self.runners.append(EmulatorRunner(w, self.emulators[sl], [v[sl] for v in self.variables],
-                                                   self.queues[w], self.barrier))
+                                                   self.queues[w], self.barrier, self.stop_flag))
 
     @staticmethod
     def _get_shared(array):
@@ -102,8 +109,10 @@ class Runners(object):
             r.start()
 
     def stop(self):
+        if self.runners:
+            self.stop_flag.value = 1
         for r in self.runners:
-            self.queues[r.id].put(None)
+            self.queues[r.id].release()
 
     def get_shared_variables(self):
         return self.variables
@@ -111,11 +120,11 @@ class Runners(object):
     def update_environments(self):
         if self.workers > 0:
             for q in self.queues:
-                q.put(True)
+                q.release()
         else:
             self.step(self.emulators, self.variables)
 
     def wait_updated(self):
         if self.workers > 0:
             for _ in range(self.workers):
-                self.barrier.get()
+                self.barrier.acquire()

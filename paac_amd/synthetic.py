@@ -39,12 +39,37 @@ def lowbias32(x):
     return x
 
 
+def lowbias32_int(x):
+    """lowbias32 on a Python int (the per-step scalars: several times faster than numpy scalar arithmetic)."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
 def synth_key(seed, env, frame_id):
     seed = int(seed)
     frame_id = int(frame_id)
-    k = lowbias32(np.uint64(seed & 0xFFFFFFFF) ^ lowbias32(np.uint64((int(env) + 0x9E3779B9) & 0xFFFFFFFF)))
-    idh = lowbias32(np.uint64(((frame_id & 0xFFFFFFFF) * 0x85EBCA6B + (frame_id >> 32) + 0x7F4A7C15) & 0xFFFFFFFF))
-    return int(lowbias32(k ^ np.uint64((seed >> 32) & 0xFFFFFFFF) ^ idh))
+    k = lowbias32_int((seed & 0xFFFFFFFF) ^ lowbias32_int(int(env) + 0x9E3779B9))
+    idh = lowbias32_int((frame_id & 0xFFFFFFFF) * 0x85EBCA6B + (frame_id >> 32) + 0x7F4A7C15)
+    return lowbias32_int(k ^ ((seed >> 32) & 0xFFFFFFFF) ^ idh)
+
+
+def _word_offsets(n):
+    return ((np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B9) + np.uint64(0x165667B1)) & M32).astype(np.uint32)
+
+
+def _lowbias32_u32(x):
+    """lowbias32 in place on a uint32 array (the arithmetic wraps by itself)."""
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
 
 
 def synth_words(key, w):
@@ -52,18 +77,22 @@ def synth_words(key, w):
     return lowbias32((np.uint64(key) + w * np.uint64(0x9E3779B9) + np.uint64(0x165667B1)) & M32).astype(np.uint32)
 
 
+_PLANE_OFF = _word_offsets(84 * 21)
+_RAW_OFF = _word_offsets(2 * 210 * 40)
+
+
 def terminal_threshold(p):
     return int(min(max(p, 0.0), 1.0) * 4294967296.0) & 0xFFFFFFFF if p < 1.0 else 0xFFFFFFFF
 
 
 def plane_a(key):
-    words = synth_words(key, np.arange(84 * 21))
-    return words.astype("<u4").view(np.uint8).reshape(84, 84)
+    words = _lowbias32_u32(_PLANE_OFF + np.uint32(key & 0xFFFFFFFF))          # == synth_words(key, arange(84 * 21))
+    return words.astype("<u4", copy=False).view(np.uint8).reshape(84, 84)
 
 
 def raw_frames_b(key):
-    words = synth_words(key ^ 0x5bd1e995, np.arange(2 * 210 * 40))
-    return words.astype("<u4").view(np.uint8).reshape(2, 210, 160)
+    words = _lowbias32_u32(_RAW_OFF + np.uint32((key ^ 0x5bd1e995) & 0xFFFFFFFF))
+    return words.astype("<u4", copy=False).view(np.uint8).reshape(2, 210, 160)
 
 
 ROW_LUT = pil_nearest_lut(210)
@@ -99,13 +128,13 @@ class SyntheticEnvironment(BaseEnvironment):
         self.frame_id += 1
         key = synth_key(self.seed, self.actor_id, self.frame_id)
         self.plane = self._plane(key)
-        new = np.empty_like(self.stack)
-        new[..., :3] = self.stack[..., 1:]
-        new[..., 3] = self.plane
-        self.stack = new
-        hr = int(lowbias32(np.uint64(key ^ 0xA511E9B3)))
+        # shift by one channel, the new plane as channel 3: one dword = the 4 channels of a pixel (little endian)
+        new32 = self.stack.view("<u4").reshape(84, 84) >> np.uint32(8)
+        new32 |= self.plane.astype(np.uint32) << np.uint32(24)
+        self.stack = new32.view(np.uint8).reshape(84, 84, 4)
+        hr = lowbias32_int(key ^ 0xA511E9B3)
         reward = float(REWARD_TABLE[(hr % 5 + a) % 5])
-        terminal = int(lowbias32(np.uint64(key ^ 0x3C6EF372))) < self.threshold
+        terminal = lowbias32_int(key ^ 0x3C6EF372) < self.threshold
         return np.copy(self.stack), reward, bool(terminal)
 
     def get_legal_actions(self):
