@@ -84,6 +84,14 @@ class ActorLearner(object):
 
         self.network_saver = self.network.make_saver()
         self.optimizer_saver = Saver(self._get_optimizer_arrays, self._set_optimizer_arrays, max_to_keep=1)
+        fmt = getattr(args, "checkpoint_format", None)
+        if fmt:
+            self.network_saver.fmt = self.optimizer_saver.fmt = fmt
+        if self.network_saver.fmt == "tf":
+            # the reference's network saver is tf.train.Saver() over ALL variables, optimizer slots included
+            # (actor_learner.py:79): a bundle its restore accepts holds them too
+            variables = self.network_saver.get_arrays
+            self.network_saver.get_arrays = lambda: dict(variables(), **self._get_optimizer_arrays())
 
     # -- optimizer slots under the reference's names ('<var>/OptimizerVariables', '<var>/OptimizerVariables_1') ----
     def _get_optimizer_arrays(self):
@@ -102,6 +110,8 @@ class ActorLearner(object):
         seen = set()
         for key, value in d.items():
             name, slot = tensor_of_key(key)
+            if slot is None:         # a bundle of all variables (the reference's network saver): the slots are taken from it
+                continue
             t = where[name]
             host[slot][t["offset"]:t["offset"] + t["size"]] = np.asarray(value, dtype=np.float32).reshape(-1)
             seen.add((name, slot))

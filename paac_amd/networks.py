@@ -107,8 +107,10 @@ class Network(object):
         """Saver over this network's variables under the reference's checkpoint names
         ('local_learning_1/conv1_weights' ... 'local_learning_2/critic_output_biases', session.checkpoint_key)."""
         from .session import Saver, checkpoint_key, tensor_of_key
+        # (a bundle written by the reference's tf.train.Saver() also holds the optimizer slots: only the variables are taken)
         return Saver(lambda: {checkpoint_key(self.name, k): v for k, v in self.get_parameters().items()},
-                     lambda d: self.set_parameters({tensor_of_key(k)[0]: v for k, v in d.items()}),
+                     lambda d: self.set_parameters({tensor_of_key(k)[0]: v for k, v in d.items()
+                                                    if tensor_of_key(k)[1] is None}),
                      max_to_keep=max_to_keep)
 
     def initialize(self, rng=None):

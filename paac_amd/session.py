@@ -8,10 +8,12 @@ It understands exactly the fetch/feed patterns of the hot path and dispatches th
 Host numpy in, host numpy out (the reference's contract); PAACLearner.train() itself uses the fused
 device-resident path and never goes through here per step.
 """
+import os
+
 import numpy as np
 import torch
 
-from . import hip_ops
+from . import hip_ops, tf_bundle
 
 
 def variable_scope(scope, tensor_name):
@@ -40,16 +42,26 @@ def _step_of(path):
 
 
 class Saver(object):
-    """Stand-in for tf.train.Saver over .npz files whose keys are the reference's variable names (checkpoint_key;
-    actor_learner.py:26-27,79-82).  Files are named '-<global step>.npz' like the reference's '-<global step>' bundles
-    (networks.py:134 parses the step from the name).  A save is atomic (temporary file + rename) and older files are
-    pruned only afterwards; a truncated or unreadable file left by a killed run is skipped on resume."""
+    """Stand-in for tf.train.Saver (actor_learner.py:26-27,79-82) in two containers, both keyed by the reference's
+    variable names (checkpoint_key) and named after the global step like the reference's '-<global step>' bundles
+    (networks.py:134 parses the step from the name):
+      * 'npz' (default): one '-<step>.npz' file;
+      * 'tf': the reference's own container, a TensorFlow V2 tensor bundle '-<step>.index' + '-<step>.data-00000-of-00001'
+        plus the `checkpoint` state file (paac_amd/tf_bundle.py) -- what the reference's Saver reads and writes.
+    restore() and latest_checkpoint() take either, whatever the saver writes.  A save is atomic (temporary files + rename,
+    the bundle's index last) and older checkpoints are pruned only afterwards; a truncated or unreadable checkpoint left by
+    a killed run is skipped on resume.  PAAC_CHECKPOINT_FORMAT / --checkpoint_format choose the written container."""
 
-    def __init__(self, get_arrays, set_arrays, max_to_keep=5):
+    def __init__(self, get_arrays, set_arrays, max_to_keep=5, fmt=None):
         self.get_arrays, self.set_arrays, self.max_to_keep = get_arrays, set_arrays, max_to_keep
+        self.fmt = fmt or os.environ.get("PAAC_CHECKPOINT_FORMAT", "npz")
+        if self.fmt not in ("npz", "tf"):
+            raise ValueError("checkpoint format %r: expected 'npz' or 'tf'" % (self.fmt,))
 
     @staticmethod
     def _readable(path):
+        if path.endswith(".index"):
+            return tf_bundle.readable(path[:-len(".index")])
         try:
             with np.load(path, allow_pickle=False) as z:
                 return len(z.files) > 0
@@ -59,8 +71,8 @@ class Saver(object):
     @staticmethod
     def checkpoints(folder):
         import glob
-        import os
-        return sorted(glob.glob(os.path.join(folder, "-*.npz")), key=_step_of)
+        found = glob.glob(os.path.join(folder, "-*.npz")) + glob.glob(os.path.join(folder, "-*.index"))
+        return sorted((p for p in found if Saver.step_of(p) is not None), key=lambda p: (_step_of(p), p))
 
     @staticmethod
     def step_of(path):
@@ -77,20 +89,34 @@ class Saver(object):
                 return path
         return None
 
+    @staticmethod
+    def _remove(path):
+        os.remove(path)
+        if path.endswith(".index") and os.path.exists(path[:-len(".index")] + tf_bundle.DATA_SUFFIX):
+            os.remove(path[:-len(".index")] + tf_bundle.DATA_SUFFIX)
+
     def save(self, session, folder, global_step):
-        import os
-        path = os.path.join(folder, "-%d.npz" % int(global_step))
-        tmp = os.path.join(folder, ".tmp-%d-%d.npz" % (int(global_step), os.getpid()))
-        with open(tmp, "wb") as f:
-            np.savez(f, **self.get_arrays())
-            f.flush()
-            os.fsync(f.fileno())
-        os.replace(tmp, path)
+        if self.fmt == "tf":
+            name = "-%d" % int(global_step)
+            path = tf_bundle.write(os.path.join(folder, name), self.get_arrays())
+            tf_bundle.write_state_file(folder, name)
+        else:
+            path = os.path.join(folder, "-%d.npz" % int(global_step))
+            tmp = os.path.join(folder, ".tmp-%d-%d.npz" % (int(global_step), os.getpid()))
+            with open(tmp, "wb") as f:
+                np.savez(f, **self.get_arrays())
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, path)
         for p in self.checkpoints(folder)[:-self.max_to_keep]:
-            os.remove(p)
+            if p != path:
+                self._remove(p)
         return path
 
     def restore(self, session, path):
+        if path.endswith(".index"):
+            self.set_arrays(tf_bundle.read(path[:-len(".index")]))
+            return
         with np.load(path, allow_pickle=False) as z:
             self.set_arrays({k: z[k] for k in z.files})
 

@@ -65,6 +65,9 @@ BUILD_FLAGS = (
      "'synthetic' (paac_amd/synthetic.py) or 'ale' (Atari through an installed Arcade Learning Environment)"),
     (("--device_preprocess",), "device_preprocess", False, bool_arg,
      "host environments hand out raw screen pairs; max + resize + frame history run on the GPU"),
+    (("--checkpoint_format",), "checkpoint_format", "npz", None,
+     "container of the checkpoints written: 'npz', or 'tf' = the reference's TensorFlow V2 tensor bundle "
+     "(.index + .data-00000-of-00001); both are read"),
 )
 
 
@@ -74,8 +77,9 @@ def get_arg_parser():
         kwargs = dict(dest=dest, default=default, help=text)
         if kind is not None:
             kwargs["type"] = kind
-        if dest in ("sampler", "emulator"):
-            kwargs["choices"] = {"sampler": ["philox", "numpy"], "emulator": ["synthetic", "ale"]}[dest]
+        if dest in ("sampler", "emulator", "checkpoint_format"):
+            kwargs["choices"] = {"sampler": ["philox", "numpy"], "emulator": ["synthetic", "ale"],
+                                 "checkpoint_format": ["npz", "tf"]}[dest]
         parser.add_argument(*options, **kwargs)
     return parser
 

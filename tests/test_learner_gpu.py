@@ -192,11 +192,22 @@ def test_choose_next_actions_dropin():
     assert np.random.get_state()[2] == rs.get_state()[2]
 
 
-def test_checkpoint_roundtrip():
-    args = make_args(game="pong", arch="NIPS", emulator_counts=4, max_local_steps=2, max_global_steps=16)
+@pytest.mark.parametrize("fmt", ["npz", "tf"])
+def test_checkpoint_roundtrip(fmt):
+    """fmt = tf: the reference's own container (TensorFlow V2 tensor bundle, paac_amd/tf_bundle.py); the network bundle
+    then holds the optimizer slots too, like the reference's tf.train.Saver() over all variables."""
+    import os
+    args = make_args(game="pong", arch="NIPS", emulator_counts=4, max_local_steps=2, max_global_steps=16,
+                     checkpoint_format=fmt)
     learner, params, _ = build_learner(args)
     learner.train()                       # 2 cycles on device envs, cleanup() saves
     saved = learner.network.get_parameters()
+    files = sorted(os.listdir(os.path.join(args.debugging_folder, "checkpoints")))
+    assert files == (["-16.npz"] if fmt == "npz" else ["-16.data-00000-of-00001", "-16.index", "checkpoint"])
+    if fmt == "tf":
+        from paac_amd import tf_bundle
+        meta = tf_bundle.entries(os.path.join(args.debugging_folder, "checkpoints", "-16"))
+        assert len(meta) == 30 and meta["local_learning_1/fc3_weights/OptimizerVariables_1"]["shape"] == (2592, 256)
     a2 = copy.copy(args)
     from paac_amd import train
     from paac_amd.paac import PAACLearner
