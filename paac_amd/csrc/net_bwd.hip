@@ -1,6 +1,7 @@
 // Backward half of the actor-critic network (see net_fwd.hip): dgrad / wgrad launches, slab finalize, launch tuning.
 #include "net_common.h"
 #include "dgrad_tower.h"
+#include "gemm3.h"
 
 namespace paac {
 
@@ -251,17 +252,55 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       static const bool pair2 = env_int("PAAC_WGRAD_PAIR", 1) != 0;
       int wcfg, wks, wxcd;
       resolve_wgrad<false, NT::H>(gw, 1, ctx->tune[OP_FC_WGRAD][cls], wcfg, wks, wxcd);
-      fc_wgrad_held = pair2 && do_conv && ctx->tower_on && wcfg == 1;
+      static const int gemm3_rows = env_int("PAAC_GEMM3_MIN_ROWS", 513);
+      fc_wgrad_held = pair2 && do_conv && ctx->tower_on && wcfg == 1 && !(batch >= gemm3_rows && (batch % 32) == 0);
       held_gw = gw;
       held_ks = wks;
       held_xcd = wxcd;
     }
-    if (!fc_wgrad_held) {
+    static const int gemm3_min_rows = env_int("PAAC_GEMM3_MIN_ROWS", 513);
+    if (!fc_wgrad_held && batch >= gemm3_min_rows && (batch % 32) == 0) {
+      // dWf[FLAT, H] = X^T dH on the LDS-tiled split-bf16 GEMM (gemm3.h), 128 x 64 tiles, whole K (= rows) per workgroup:
+      // written straight into the flat gradient; the row-block-0 workgroups also leave the bias gradient (column sums of dH)
+      ProfScope ps(ctx, F_FC_WGRAD, batch, s);
+      Gemm3Args a;
+      memset(&a, 0, sizeof(a));
+      a.A = xf; a.lda = NT::FLAT;            // given transposed: [K = rows, M = FLAT]
+      a.B = ctx->dh; a.ldb = NT::H;          // [K = rows, N = H]
+      a.out = grad + L.offset[i_wf]; a.ldo = NT::H;
+      a.colsum_out = grad + L.offset[i_wf + 1];
+      a.M = NT::FLAT; a.N = NT::H; a.K = batch;
+      using D = Gemm3<false, false, EPI_SLAB, 4, 2, 2, 2>;
+      a.MB = (NT::FLAT + D::TM - 1) / D::TM;
+      a.NB = (NT::H + D::TN - 1) / D::TN;
+      a.S = 1;
+      a.stages_per_split = batch / 32;
+      prof_mix(6);
+      launch_k(gemm3_kernel<D>, dim3((unsigned)(a.MB * a.NB)), dim3(D::THREADS), s, PROF_WHOLE, a);
+    } else if (!fc_wgrad_held) {
       ProfScope ps(ctx, F_FC_WGRAD, batch, s);
       launch_wgrad<typename NT::GFC, false, NT::H>(gw, 1, ctx->tune[OP_FC_WGRAD][cls], s);
     }
     ProfScope ps(ctx, F_FC_DGRAD, batch, s);
-    launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(gd, 1, ctx->tune[OP_FC_DGRAD][cls], s);
+    if (batch >= gemm3_min_rows && (NT::H % 32) == 0) {
+      // dX = dH * Wf^T on the LDS-tiled split-bf16 GEMM (gemm3.h); B = the fc weights as stored ([N = FLAT, K = H])
+      Gemm3Args a;
+      memset(&a, 0, sizeof(a));
+      a.A = ctx->dh; a.lda = NT::H;
+      a.B = wf; a.ldb = NT::H;
+      a.out = dxf; a.ldo = NT::FLAT;
+      a.mask = xf;
+      a.M = batch; a.N = NT::FLAT; a.K = NT::H;
+      using D = Gemm3<true, true, EPI_MASK>;
+      a.MB = (batch + D::TM - 1) / D::TM;
+      a.NB = (NT::FLAT + D::TN - 1) / D::TN;
+      a.S = 1;
+      a.stages_per_split = NT::H / 32;
+      prof_mix(6);
+      launch_k(gemm3_kernel<D>, dim3((unsigned)(a.MB * a.NB)), dim3(D::THREADS), s, PROF_WHOLE, a);
+    } else {
+      launch_dgrad<typename NT::GFCH, NT::FLAT, NT::H, EPI_MASK>(gd, 1, ctx->tune[OP_FC_DGRAD][cls], s);
+    }
   }
   if (!do_conv) return 0;
   if constexpr (NT::NCONV == 3) {

@@ -6,6 +6,7 @@
 #include "net_common.h"
 #include "tower.h"
 #include "fc_heads.h"
+#include "gemm3.h"
 
 namespace paac {
 
@@ -83,6 +84,32 @@ static int launch_fwd(const GemmArgs& g, Tune t, hipStream_t s) {
     default: break;
   }
   return ksplit;
+}
+
+// fc forward at large training batches on the LDS-tiled split-bf16 GEMM (gemm3.h): split-K slabs like launch_fwd's
+// EPI_SLAB form.  Returns the number of slabs, 0 when the shape does not qualify (the caller takes the dmm path).
+static int launch_fc_gemm3(const float* x, const float* wf, float* slab, int batch, int K, int H, hipStream_t s) {
+  static const int min_rows = env_int("PAAC_GEMM3_MIN_ROWS", 513);
+  if (batch < min_rows || (K % 32) != 0) return 0;
+  Gemm3Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = x; a.lda = K;
+  a.B = wf; a.ldb = H;
+  a.out = slab; a.ldo = H;
+  a.M = batch; a.N = H; a.K = K;
+  using D = Gemm3<true, false, EPI_SLAB>;
+  a.MB = (batch + D::TM - 1) / D::TM;
+  a.NB = (H + D::TN - 1) / D::TN;
+  // K splits: enough workgroups for about one round of the 256 CUs (one workgroup per CU: 96 KB of LDS)
+  const int stages = K / 32, tiles = a.MB * a.NB;
+  int S = (256 + tiles / 2) / tiles;
+  S = S < 1 ? 1 : (S > FC_SPLITS_MAX ? FC_SPLITS_MAX : S);
+  a.stages_per_split = (stages + S - 1) / S;
+  a.S = (stages + a.stages_per_split - 1) / a.stages_per_split;
+  a.slab_stride = (long)batch * H;
+  prof_mix(6);
+  launch_k(gemm3_kernel<D>, dim3((unsigned)(a.MB * a.NB * a.S)), dim3(D::THREADS), s, PROF_WHOLE, a);
+  return a.S;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -251,7 +278,8 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     ProfScope ps(ctx, F_FC_FWD, batch, s);
     GemmArgs g = make_args(last, (size_t)batch * NT::FLAT * 4, wf, (size_t)NT::FLAT * NT::H * 4, W.fc_slab, nullptr, batch, NT::H, NT::FLAT, NT::H, NT::H);
     g.slab_rows = batch;
-    splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
+    splits = launch_fc_gemm3(last, wf, W.fc_slab, batch, NT::FLAT, NT::H, s);
+    if (splits == 0) splits = launch_fwd<typename NT::GFC, false, NT::H, EPI_SLAB>(g, ctx->tune[OP_FC_FWD][cls], s);
   }
   if (wsi == 1) ctx->heads_pending_rows = 0;
   if (trunk_only && wsi == 1) {      // the backward's first launch finishes the heads (heads.h: heads_train_kernel)
