@@ -58,6 +58,41 @@ with open("profiles/%s_pmc_traffic.csv" % tag, "w") as f:
         f.write("\"%s\",%s,%d,%.1f,%.0f,%.1f,%.0f\n" % (k[0], k[1], fe[k][1], fk, 2 * fk * 1024, wk, tot))
 json.dump(traffic, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 
+# 2b. MFMA utilisation per kernel (its own pass): SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over the
+# SIMDs; GRBM_GUI_ACTIVE is the kernel's clock cycles summed over the 8 XCDs -> share = busy / (GUI / 8 * 256 CUs * 4 SIMDs)
+try:
+    f = glob.glob(os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(f)):
+        k = (short(r['Kernel_Name']), r.get('Grid_Size', ''))
+        agg[k][r['Counter_Name']][0] += float(r['Counter_Value'])
+        agg[k][r['Counter_Name']][1] += 1
+    with open("profiles/%s_pmc_mfma.csv" % tag, "w") as out:
+        # average duration of the same kernel in the kernel-trace pass (un-countered): the counter pass serialises the
+        # dispatches and GRBM_GUI_ACTIVE of a 10 us kernel includes its drain, so the share against wall time x 2.4 GHz is
+        # given beside the derived-counter formula MfmaUtil = busy / (GUI_ACTIVE * SIMDs)
+        dur = collections.defaultdict(lambda: [0.0, 0])
+        for r in rows:
+            wgs = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+            d = dur[(short(r['Kernel_Name']), str(wgs))]
+            d[0] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            d[1] += 1
+        out.write("kernel,grid_size,launches,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,GRBM_GUI_ACTIVE_per_launch,SQ_BUSY_CYCLES_per_launch,"
+                  "mfma_busy_share_vs_gui_active,avg_duration_us_kernel_trace_pass,mfma_busy_share_vs_duration_at_2.4GHz\n")
+        def per(k, c):
+            v = agg[k].get(c)
+            return v[0] / v[1] if v and v[1] else 0.0
+        for k in sorted(agg, key=lambda k: -per(k, "SQ_VALU_MFMA_BUSY_CYCLES") * agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1]):
+            busy, gui, sq = per(k, "SQ_VALU_MFMA_BUSY_CYCLES"), per(k, "GRBM_GUI_ACTIVE"), per(k, "SQ_BUSY_CYCLES")
+            share = busy / (gui / 8.0 * 256 * 4) if gui > 0 else 0.0
+            dk = dur.get(k)
+            us = dk[0] / dk[1] / 1000.0 if dk and dk[1] else 0.0
+            share2 = busy / 1024.0 / (us * 2400.0) if us > 0 else 0.0
+            out.write("\"%s\",%s,%d,%.0f,%.0f,%.0f,%.4f,%.2f,%.4f\n" % (k[0], k[1], agg[k]["GRBM_GUI_ACTIVE"][1], busy, gui, sq, share,
+                                                                  us, share2))
+except (IndexError, KeyError) as exc:
+    print("no MFMA pass:", exc)
+
 # per kernel-family table in bench.py's naming ("family[batch=B]"): dmm families are read off the template arguments
 # (geometry + fragment pattern; the smaller launch of a family is the acting batch), the fused kernels off their names
 PATTERNS = [("conv1_wgrad", "G84,84,4,20,20", "ap1"), ("conv2_wgrad", "G20,20,", "ap1"),
@@ -78,8 +113,11 @@ for name, gpat, ap in PATTERNS:
         fam["%s[batch=%d]" % (name, b)] = traffic["%s|%s" % k]
 FUSED = [("conv_tower", "tower_kernel<TowerGeom", None), ("fc_fwd", "fc_heads_kernel", n_act),
          ("sample_env_step", "synth_step_a_mth_kernel", n_act), ("sample_env_step", "synth_step_a_mt_kernel", n_act),
-         ("conv3_dgrad", "dgrad_tower_kernel", n_train), ("heads_fwd", "heads_fwd_kernel", n_fwd),
-         ("heads_bwd", "heads_bwd_kernel", n_train), ("grad_finalize", "grad_finalize_kernel", n_train),
+         ("dgrad_tower", "dgrad_tower_kernel", n_train), ("heads_fwd", "heads_fwd_kernel", n_fwd),
+         ("heads_bwd", "heads_bwd_kernel", n_train), ("heads_bwd", "heads_train_kernel", n_train),
+         ("fc_conv3_wgrad", "dmm_pair_kernel<Dmm<Geom<1, 1, 3136", n_train),
+         ("conv2_conv1_wgrad", "dmm_pair_kernel<Dmm<Geom<20, 20, 32", n_train),
+         ("grad_finalize", "grad_finalize_kernel", n_train),
          ("nstep_returns", "nstep_returns_kernel", n_train)]
 for name, pat, b in FUSED:
     ks = sorted([k for k in fe if pat in k[0]], key=lambda k: traffic["%s|%s" % k])

@@ -14,6 +14,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B -
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B --steps 12 --warmup 4 --windows 1 --no-cpu-baseline --no-roofline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write done"
+# MFMA utilisation (north_star): matrix-pipe busy cycles per kernel against the kernel's own clock cycles, its own pass
+rocprofv3 -L > $OUT/counters_available.txt 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $B --steps 12 --warmup 4 --windows 1 --no-cpu-baseline --no-roofline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
+echo "pmc mfma done"
 python3 $B --envs 256 --no-cpu-baseline --steps 100 --warmup 10 > $OUT/bench_256envs.json 2> $OUT/b256.err
 python3 $B --envs 128 --tmax 20 --game seaquest --no-cpu-baseline --steps 40 --warmup 8 > $OUT/bench_seaquest_128envs_tmax20.json 2> $OUT/b128.err
 python3 $B --game qbert --no-cpu-baseline > $OUT/bench_qbert_32envs.json 2> $OUT/bq.err
