@@ -19,7 +19,8 @@
 
 namespace paac {
 
-constexpr int kFcHeadsMaxRows = 64;
+constexpr int kFcHeadsMaxRows = 64;      // one finishing workgroup (it can be workgroup 0 of the sampler + env-step launch)
+constexpr int kFcHeadsMidRows = 256;     // acting batches up to here take the same fc kernel, finished by heads_finish_rows_kernel
 
 // Packed fc weights for fc_heads_kernel: wfp[tile nt][group g][lane][4] = Wf[16 g + 4 kq + s][16 nt + li], s = 0..3 (lane =
 // 16 kq + li): the B fragment of one 16-wide K group is ONE 16-byte load per lane, 1 KB contiguous per wave (the plain
@@ -216,6 +217,36 @@ static __global__ __launch_bounds__(256) void heads_finish_kernel(const float* _
   __shared__ float lg_s[kFcHeadsMaxRows * 33];
   heads_from_partials(partial, ntiles, B, A, ba, bc, lg_s, nullptr, logits_ws, probs_ws, values_ws, logits_out, probs_out,
                       values_out);
+}
+
+// The heads finish for acting batches beyond one workgroup's reach (64 < B <= 256 rows: the 128- and 256-environment
+// shards): workgroup w finishes rows [w * rpw, ...) with rpw = 256 / (A + 1) -- one (row, output) per thread, the same sums
+// in the same order as heads_from_partials -- instead of a per-row workgroup re-reading 64 KB of split-K slabs per step.
+static __global__ __launch_bounds__(256) void heads_finish_rows_kernel(const float* __restrict__ partial, int ntiles, int B,
+                                                                int A, int rpw, const float* __restrict__ ba,
+                                                                const float* __restrict__ bc, float* __restrict__ logits_ws,
+                                                                float* __restrict__ probs_ws, float* __restrict__ values_ws,
+                                                                float* __restrict__ logits_out, float* __restrict__ probs_out,
+                                                                float* __restrict__ values_out) {
+  __shared__ float lg_s[256];
+  const int row0 = blockIdx.x * rpw;
+  const int rows = min(rpw, B - row0);
+  const int n = rows * (A + 1), n_total = B * (A + 1);
+  const int tid = threadIdx.x;
+  if (tid < n) {
+    const int a = tid % (A + 1);
+    float acc = (a < A) ? ba[a] : bc[0];
+    float v[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n_total + (size_t)row0 * (A + 1) + tid];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc += (t < ntiles) ? v[t] : 0.f;
+    lg_s[tid] = acc;
+  }
+  __syncthreads();
+  auto at = [](float* p, long off) { return p ? p + off : p; };
+  heads_softmax_store(rows, A, lg_s, nullptr, at(logits_ws, (long)row0 * A), at(probs_ws, (long)row0 * A), at(values_ws, row0),
+                      at(logits_out, (long)row0 * A), at(probs_out, (long)row0 * A), at(values_out, row0));
 }
 
 }  // namespace paac

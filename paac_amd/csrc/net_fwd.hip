@@ -215,7 +215,12 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   const bool small_tail = batch <= kFcHeadsMaxRows && !ph.enabled && !st.enabled;   // fc + head partials kernel (fc_heads.h)
   // conv3 -> fc hand-off in the fc kernel's fragment order: rows are padded to 16 inside the activation buffer (max_batch
   // is rounded up at allocation)
-  const bool packed3 = tower && small_tail && !keep_acts;
+  // ... and acting batches of up to 256 rows (the 128- / 256-environment shards) take the same fc kernel, finished by a
+  // few workgroups (heads_finish_rows_kernel) instead of split-K slabs + a per-row heads launch
+  const bool mid_tail = !small_tail && tower && !keep_acts && wsi == 0 && batch <= kFcHeadsMidRows && !ph.enabled &&
+                        !st.enabled && !defer_heads && !trunk_only;
+  // (measured at 128 rows: fragment-order hand-off tower 16.5 + fc 8.7 us, plain rows 15.2 + 10.4)
+  const bool packed3 = tower && (small_tail || mid_tail) && !keep_acts;
   if (!ctx->managed_weights && (tower || batch <= kFcHeadsMaxRows)) launch_pack_weights(ctx, params, s);
   if (tower) {
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
@@ -245,7 +250,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   }
   // Small acting / evaluation batches: fc with the head contractions folded into its epilogue (fc_heads.h), then the
   // head finish -- as its own one-workgroup launch here, or (defer_heads) inside the caller's sampler launch.
-  if (small_tail) {
+  if (small_tail || mid_tail) {
     if (wsi == 1) ctx->heads_pending_rows = 0;
     constexpr int NTILES = NT::H / 16;
     float* partial = W.fc_slab;      // [NTILES][batch][A + 1]: fits the split-K slab buffer
@@ -262,7 +267,12 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
                  last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial,
                  keep_h ? W.h : (float*)nullptr);
     }
-    if (!defer_heads) {
+    if (mid_tail) {
+      ProfScope ps(ctx, F_HEADS_FWD, batch, s);
+      const int rpw = 256 / (A + 1);
+      launch_k(heads_finish_rows_kernel, dim3((batch + rpw - 1) / rpw), dim3(256), s, PROF_WHOLE, (const float*)partial, NTILES,
+               batch, A, rpw, ba, bc, W.logits, W.probs, W.values, logits, probs, values);
+    } else if (!defer_heads) {
       ProfScope ps(ctx, F_HEADS_FWD, batch, s);
       launch_k(heads_finish_kernel, dim3(1), dim3(256), s, PROF_WHOLE, (const float*)partial, NTILES, batch, A, ba, bc,
                W.logits, W.probs, W.values, logits, probs, values);

