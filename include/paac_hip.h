@@ -29,7 +29,12 @@ typedef struct paac_ctx paac_ctx;
 typedef struct paac_graph paac_graph;
 typedef void* paac_stream_t; /* hipStream_t */
 
-enum { PAAC_ARCH_NIPS = 0, PAAC_ARCH_NATURE = 1 };   /* networks.py:138-151 / :154-169 */
+enum { PAAC_ARCH_NIPS = 0, PAAC_ARCH_NATURE = 1,     /* networks.py:138-151 / :154-169 */
+       /* a user architecture (networks.py:117-120, README.md:80-83: "subclass the trunk"): the same trunk family -- conv
+        * 8x8 / 4, conv 4x4 / 2 [, conv 3x3 / 1], fc -- with the user's filter counts (multiples of 16) and fc width (a
+        * multiple of 256).  An architecture here is a compiled geometry: paac_amd/build.py builds a library for it on
+        * demand (-DPAAC_USER_ARCH ...), which then serves PAAC_ARCH_NATURE and PAAC_ARCH_USER (not PAAC_ARCH_NIPS). */
+       PAAC_ARCH_USER = 2 };
 enum { PAAC_CLIP_IGNORE = 0, PAAC_CLIP_GLOBAL = 1 }; /* actor_learner.py:51-59 ('local' is broken upstream) */
 
 #define PAAC_MAX_TENSORS 12
@@ -283,6 +288,10 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
  * (-1 = size heuristic), ksplit = blockIdx.z K split (0 = heuristic), xcd_dim = grid dimension tied to the XCD. */
 int paac_debug_set_tuning(paac_ctx* ctx, int op, int batch_class, int cfg, int ksplit, int xcd_dim);
 int paac_debug_get_tuning(paac_ctx* ctx, int op, int batch_class, int* cfg, int* ksplit, int* xcd_dim);
+
+/* The user architecture compiled into this library: returns 1 and fills nconv (2 or 3), filters3[3] (0 for an absent third
+ * layer) and fc_width; returns 0 (and zeros) for the stock library. */
+int paac_user_arch(int32_t* nconv, int32_t* filters3, int32_t* fc_width);
 
 /* Diagnostic: writes {s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks} to out2_dev[0..1]. */
 int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);

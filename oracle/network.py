@@ -36,7 +36,10 @@ CRITIC_COEF = 0.25                      # policy_v_network.py:53
 
 
 def arch_key(arch):
-    """train.py:63-66: 'NIPS' selects NIPS, anything else selects Nature."""
+    """train.py:63-66: 'NIPS' selects NIPS, anything else selects Nature -- except a name a test registered in ARCHS (a
+    user architecture, networks.py:117-120: same layer helpers, other widths)."""
+    if arch in ARCHS:
+        return arch
     return "NIPS" if arch == "NIPS" else "NATURE"
 
 

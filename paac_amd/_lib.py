@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PAAC_HIP_LIB") or os.path.join(HERE, "libpaac_hip.so"
 
 MAX_TENSORS = 12
 PROF_FAMILIES = 16
-ARCH_NIPS, ARCH_NATURE = 0, 1
+ARCH_NIPS, ARCH_NATURE, ARCH_USER = 0, 1, 2
 CLIP_IGNORE, CLIP_GLOBAL = 0, 1
 
 
@@ -100,11 +100,31 @@ _SIGNATURES = {
     "paac_prof_read": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_int]),
     "paac_prof_read_mix": (c_int, [c_void_p, POINTER(c_int32), c_int]),
     "paac_prof_name": (c_char_p, [c_int]),
+    "paac_user_arch": (c_int, [POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 
 _lib = None
+
+
+def use_library(path):
+    """Choose the library file this process loads (a build for a user architecture, paac_amd.build.build_user_arch).  One
+    library per process: it must be chosen before the first call into it."""
+    global LIB_PATH
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        raise PaacHipError("%s is already loaded: a process holds ONE geometry besides Nature -- choose the user "
+                           "architecture before anything touches the library" % LIB_PATH)
+    LIB_PATH = path
+
+
+def user_arch():
+    """-> (convs [(filters, size, stride), ...], fc width) compiled into the loaded library, or None (stock library)."""
+    nconv, filters, fc = c_int32(), (c_int32 * 3)(), c_int32()
+    if not load().paac_user_arch(ctypes.byref(nconv), filters, ctypes.byref(fc)):
+        return None
+    sizes = [(8, 4), (4, 2), (3, 1)]
+    return [(int(filters[i]),) + sizes[i] for i in range(nconv.value)], int(fc.value)
 
 
 def load():

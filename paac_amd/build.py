@@ -49,8 +49,38 @@ def build(force=False, verbose=True, extra_flags=(), lib_path=None, obj_suffix="
     return lib
 
 
+def user_arch_library(convs, fc):
+    """In-tree path of the library compiled for a user architecture (convs: [(filters, size, stride), ...])."""
+    tag = "_".join(str(f) for f, _, _ in convs) + "_%d" % fc
+    return os.path.join(HERE, "libpaac_hip_user_%s.so" % tag), "_user_" + tag
+
+
+def build_user_arch(convs, fc, verbose=False):
+    """Compile libpaac_hip for a user architecture of the reference's trunk family (include/paac_hip.h: PAAC_ARCH_USER):
+    conv 8x8 / 4 -> conv 4x4 / 2 [-> conv 3x3 / 1] -> fc, with the given filter counts and fc width.  The geometry is a
+    compile-time template argument of every kernel, so a new architecture is a new build (about a minute of hipcc), cached
+    in-tree by its shape.  Returns the library path."""
+    convs = [tuple(int(v) for v in c) for c in convs]
+    family = [(8, 4), (4, 2), (3, 1)]
+    if len(convs) not in (2, 3) or any((k, s) != family[i] for i, (_, k, s) in enumerate(convs)):
+        raise NotImplementedError("user architectures share the reference trunks' layer shapes -- conv 8x8 stride 4, conv "
+                                  "4x4 stride 2[, conv 3x3 stride 1] -- with their own filter counts; got %r" % (convs,))
+    if any(f % 16 or f < 16 for f, _, _ in convs) or fc % 256 or fc < 256:
+        raise NotImplementedError("filter counts must be multiples of 16 and the fc width a multiple of 256 (MFMA tiles); "
+                                  "got %r, fc %d" % (convs, fc))
+    lib, suffix = user_arch_library(convs, fc)
+    flags = ["-DPAAC_USER_ARCH", "-DPAAC_USER_NCONV=%d" % len(convs), "-DPAAC_USER_C1=%d" % convs[0][0],
+             "-DPAAC_USER_C2=%d" % convs[1][0], "-DPAAC_USER_C3=%d" % (convs[2][0] if len(convs) == 3 else 0),
+             "-DPAAC_USER_H=%d" % fc]
+    return build(verbose=verbose, extra_flags=flags, lib_path=lib, obj_suffix=suffix)
+
+
 if __name__ == "__main__":
-    if "--stamps" in sys.argv:
+    if "--user-arch" in sys.argv:        # e.g. --user-arch 32,64,64,1024 (2 or 3 filter counts, then the fc width)
+        v = [int(x) for x in sys.argv[sys.argv.index("--user-arch") + 1].split(",")]
+        sizes = [(8, 4), (4, 2), (3, 1)]
+        print(build_user_arch([(f,) + sizes[i] for i, f in enumerate(v[:-1])], v[-1], verbose=True))
+    elif "--stamps" in sys.argv:
         print(build(extra_flags=["-DPAAC_DMM_STAMPS"], lib_path=os.path.join(HERE, "libpaac_hip_stamps.so"),
                     obj_suffix="_stamps"))
     else:

@@ -29,6 +29,15 @@ ArchSpec arch_spec(int arch) {
     s.conv[2] = ConvSpec{9, 9, 64, 7, 7, 64, 3, 1};
     s.flat = 3136;
     s.fc = 512;
+#ifdef PAAC_USER_ARCH
+  } else if (arch == PAAC_ARCH_USER) {
+    s.nconv = PAAC_USER_NCONV;
+    s.conv[0] = ConvSpec{84, 84, 4, 20, 20, PAAC_USER_C1, 8, 4};
+    s.conv[1] = ConvSpec{20, 20, PAAC_USER_C1, 9, 9, PAAC_USER_C2, 4, 2};
+    if (PAAC_USER_NCONV == 3) s.conv[2] = ConvSpec{9, 9, PAAC_USER_C2, 7, 7, PAAC_USER_C3, 3, 1};
+    s.flat = PAAC_USER_NCONV == 3 ? 49 * PAAC_USER_C3 : 81 * PAAC_USER_C2;
+    s.fc = PAAC_USER_H;
+#endif
   } else {
     s.nconv = 2;
     s.conv[0] = ConvSpec{84, 84, 4, 20, 20, 16, 8, 4};
@@ -37,6 +46,15 @@ ArchSpec arch_spec(int arch) {
     s.fc = 256;
   }
   return s;
+}
+
+// which of the library's two compiled geometries besides Nature: the reference's NIPS trunk, or a user architecture
+bool arch_supported(int arch) {
+#ifdef PAAC_USER_ARCH
+  return arch == PAAC_ARCH_NATURE || arch == PAAC_ARCH_USER;
+#else
+  return arch == PAAC_ARCH_NATURE || arch == PAAC_ARCH_NIPS;
+#endif
 }
 
 int64_t wslab_floats_needed(int arch);
@@ -66,7 +84,8 @@ int paac_version(void) { return 100; }
 
 int paac_param_layout(int arch, int num_actions, paac_layout* out) {
   PAAC_REQUIRE(out, "paac_param_layout: null out");
-  PAAC_REQUIRE(arch == PAAC_ARCH_NIPS || arch == PAAC_ARCH_NATURE, "paac_param_layout: arch %d", arch);
+  PAAC_REQUIRE(arch_supported(arch), "paac_param_layout: arch %d is not compiled into this library (a library holds Nature "
+               "and either the NIPS geometry or one user architecture, paac_user_arch)", arch);
   PAAC_REQUIRE(num_actions >= 2 && num_actions <= 32, "paac_param_layout: num_actions %d not in [2,32]", num_actions);
   memset(out, 0, sizeof(*out));
   const ArchSpec s = arch_spec(arch);
@@ -479,6 +498,24 @@ int paac_prof_read_mix(paac_ctx* ctx, int32_t* mix_out, int max_events) {
   int n = 0;
   for (int i = 0; i < ctx->ev_count && n < max_events; ++i) mix_out[n++] = ctx->ev_mix[i];
   return n;
+}
+
+int paac_user_arch(int32_t* nconv, int32_t* filters3, int32_t* fc_width) {
+#ifdef PAAC_USER_ARCH
+  if (nconv) *nconv = PAAC_USER_NCONV;
+  if (filters3) {
+    filters3[0] = PAAC_USER_C1;
+    filters3[1] = PAAC_USER_C2;
+    filters3[2] = PAAC_USER_NCONV == 3 ? PAAC_USER_C3 : 0;
+  }
+  if (fc_width) *fc_width = PAAC_USER_H;
+  return 1;
+#else
+  if (nconv) *nconv = 0;
+  if (fc_width) *fc_width = 0;
+  if (filters3) filters3[0] = filters3[1] = filters3[2] = 0;
+  return 0;
+#endif
 }
 
 const char* paac_prof_name(int family) {

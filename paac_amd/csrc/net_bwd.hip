@@ -463,14 +463,17 @@ int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, c
   }
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return backward_impl<NatureNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, rt, s);
-  return backward_impl<NipsNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, rt, s);
+  return backward_impl<OtherNet>(ctx, params, states, actions, y, adv, batch, beta, grad, loss_out, phase, rt, s);
 }
 
 int64_t wslab_floats_needed(int arch) {
   if (arch == PAAC_ARCH_NATURE)
     return (int64_t)W_SPLITS_MAX * ((NatureNet::G3::FEATS + 1) * NatureNet::C3 + (NatureNet::G2::FEATS + 1) * NatureNet::C2 +
                                     257 * NatureNet::C1);
-  return (int64_t)W_SPLITS_MAX * ((NipsNet::G2::FEATS + 1) * NipsNet::C2 + 257 * NipsNet::C1);
+  if (OtherNet::NCONV == 3)
+    return (int64_t)W_SPLITS_MAX * ((OtherNet::G3::FEATS + 1) * OtherNet::C3 + (OtherNet::G2::FEATS + 1) * OtherNet::C2 +
+                                    257 * OtherNet::C1);
+  return (int64_t)W_SPLITS_MAX * ((OtherNet::G2::FEATS + 1) * OtherNet::C2 + 257 * OtherNet::C1);
 }
 
 }  // namespace paac

@@ -31,6 +31,31 @@ struct NipsNet {
   using G2D = Geom<9, 9, 32, 10, 10, 1, 1, 1, 2, 2>;
 };
 
+// A user architecture (reference networks.py:117-120, README "new architectures"): the same trunk family -- conv 8x8 / 4,
+// conv 4x4 / 2 [, conv 3x3 / 1], fc -- with the user's filter counts and fc width, compiled into its own library
+// (paac_amd/build.py: build_user_arch; -DPAAC_USER_ARCH -DPAAC_USER_NCONV=.. -DPAAC_USER_C1=.. ...).  It takes the place
+// of the NIPS geometry in the two-way dispatch: such a library serves PAAC_ARCH_NATURE and PAAC_ARCH_USER.
+#ifdef PAAC_USER_ARCH
+struct UserNet {
+  static constexpr int NCONV = PAAC_USER_NCONV, C1 = PAAC_USER_C1, C2 = PAAC_USER_C2;
+  static constexpr int C3 = (PAAC_USER_NCONV == 3) ? PAAC_USER_C3 : PAAC_USER_C2, H = PAAC_USER_H;
+  static constexpr int FLAT = (PAAC_USER_NCONV == 3) ? 49 * C3 : 81 * C2;
+  static_assert(NCONV == 2 || NCONV == 3, "two or three conv layers");
+  static_assert(C1 % 16 == 0 && C2 % 16 == 0 && C3 % 16 == 0 && C1 >= 16 && C2 >= 16 && C3 >= 16, "filter counts: multiples of 16");
+  static_assert(H % 256 == 0 && H >= 256, "fc width: a multiple of 256");
+  using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
+  using G2 = Geom<20, 20, C1, 9, 9, 2, 0, 0, 4, 4>;
+  using G3 = Geom<9, 9, C2, 7, 7, 1, 0, 0, 3, 3>;
+  using GFC = Geom<1, 1, FLAT, 1, 1, 1, 0, 0, 1, 1>;
+  using GFCH = Geom<1, 1, H, 1, 1, 1, 0, 0, 1, 1>;
+  using G3D = Geom<7, 7, C3, 9, 9, 1, 2, 2, 3, 3>;
+  using G2D = Geom<9, 9, C2, 10, 10, 1, 1, 1, 2, 2>;
+};
+using OtherNet = UserNet;
+#else
+using OtherNet = NipsNet;
+#endif
+
 constexpr int W_SPLITS_MAX = 64;
 
 #ifdef PAAC_DMM_STAMPS

@@ -125,7 +125,7 @@ int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
       launch_k(pack_fc_kernel<NatureNet::FLAT, NatureNet::H>, dim3((NatureNet::FLAT / 16) * (NatureNet::H / 16) * 64 / 256),
                dim3(256), s, PROF_NONE, wf, out);
     else
-      launch_k(pack_fc_kernel<NipsNet::FLAT, NipsNet::H>, dim3((NipsNet::FLAT / 16) * (NipsNet::H / 16) * 64 / 256), dim3(256),
+      launch_k(pack_fc_kernel<OtherNet::FLAT, OtherNet::H>, dim3((OtherNet::FLAT / 16) * (OtherNet::H / 16) * 64 / 256), dim3(256),
                s, PROF_NONE, wf, out);
   }
   if (!ctx->tower_on) return 0;
@@ -316,7 +316,7 @@ int launch_forward(paac_ctx* ctx, int ws, const float* params, const uint8_t* st
   memset(&st, 0, sizeof(st));
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
-  return forward_impl<NipsNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
+  return forward_impl<OtherNet>(ctx, ws, params, states, batch, logits, probs, values, ph, st, s);
 }
 
 // Training forward up to the fc layer's split-K slabs (batches above the small-batch tail only; smaller ones run the
@@ -328,7 +328,7 @@ int launch_forward_trunk_train(paac_ctx* ctx, const float* params, const uint8_t
   memset(&st, 0, sizeof(st));
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, false, true);
-  return forward_impl<NipsNet>(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, false, true);
+  return forward_impl<OtherNet>(ctx, 1, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, false, true);
 }
 
 // The heads launch a trunk-only training forward left out (a backward that cannot fuse it runs it first).
@@ -347,14 +347,14 @@ int launch_deferred_heads(paac_ctx* ctx, const float* params, hipStream_t s) {
   const float *bf = params + L.offset[nt - 5], *wa = params + L.offset[nt - 4], *ba = params + L.offset[nt - 3],
               *wc = params + L.offset[nt - 2], *bc = params + L.offset[nt - 1];
   ProfScope ps(ctx, F_HEADS_FWD, rows, s);
-  if (H == 512)
-    launch_heads_fwd<512>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa, ba, wc,
-                          bc, A, W.h, W.logits, W.probs, W.values, (float*)nullptr, (float*)nullptr, (float*)nullptr, ph, rows,
-                          st);
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    launch_heads_fwd<NatureNet::H>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa,
+                                   ba, wc, bc, A, W.h, W.logits, W.probs, W.values, (float*)nullptr, (float*)nullptr,
+                                   (float*)nullptr, ph, rows, st);
   else
-    launch_heads_fwd<256>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa, ba, wc,
-                          bc, A, W.h, W.logits, W.probs, W.values, (float*)nullptr, (float*)nullptr, (float*)nullptr, ph, rows,
-                          st);
+    launch_heads_fwd<OtherNet::H>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa,
+                                  ba, wc, bc, A, W.h, W.logits, W.probs, W.values, (float*)nullptr, (float*)nullptr,
+                                  (float*)nullptr, ph, rows, st);
   return 0;
 }
 
@@ -373,7 +373,7 @@ int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* stat
   *ntiles = ctx->spec.fc / 16;
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
-  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+  return forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
 }
 
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
@@ -391,7 +391,7 @@ int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* sta
   ph.actions = actions;
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, st, s);
-  return forward_impl<NipsNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, st, s);
+  return forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, probs, values, ph, st, s);
 }
 
 int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,

@@ -6,9 +6,12 @@ parameter layout) plus the flat fp32 parameter buffer in HBM.  The arithmetic --
 softmax head (:84-89) -- is executed by libpaac_hip.so (csrc/net_fwd.hip, csrc/net_bwd.hip).  The attribute names the learner and
 test.py touch (`input_ph`, `output`, `init(checkpoint_folder, saver, session)`) are kept.
 
-New architectures: the reference lets users subclass Network and set `self.output`; here an architecture is a
-compiled kernel chain, so adding one means adding its geometry to csrc/net_common.h (NatureNet / NipsNet) and an
-entry in ARCH_IDS.
+New architectures: the reference lets users subclass Network and set `self.output` (networks.py:117-120,
+README.md:80-83).  Here an architecture is a compiled kernel chain -- its geometry is a template argument of every kernel
+-- so `define_architecture(name, convs, fc)` compiles a library for it on first use (paac_amd/build.py:
+build_user_arch, about a minute of hipcc, cached in-tree) and returns the trunk class to mix into PolicyVNetwork, exactly
+like NIPSNetwork / NatureNetwork.  Supported: the reference trunks' layer shapes (conv 8x8 / 4, conv 4x4 / 2[, conv 3x3 /
+1], fc) with any filter counts that are multiples of 16 and an fc width that is a multiple of 256.
 """
 import glob
 import logging
@@ -130,6 +133,32 @@ class Network(object):
             saver.restore(session, path)
             last_saving_step = int(path[path.rindex('-') + 1:].split('.')[0])
         return last_saving_step
+
+
+def define_architecture(name, convs, fc, build=True):
+    """A user architecture: `convs` = [(filters, size, stride), ...] (2 or 3 layers), `fc` = width of the hidden fc layer.
+    Builds (or finds) the library compiled for that geometry, makes it THE library of this process and returns a Network
+    subclass -- use it like the reference's trunks:  class MyNet(PolicyVNetwork, define_architecture(...)): pass."""
+    from . import build as builder
+    convs = [tuple(int(v) for v in c) for c in convs]
+    lib = builder.build_user_arch(convs, int(fc)) if build else builder.user_arch_library(convs, int(fc))[0]
+    _lib.use_library(lib)
+    have = _lib.user_arch()
+    if have != (convs, int(fc)):
+        raise RuntimeError("the loaded library holds the user architecture %r, not %r" % (have, (convs, int(fc))))
+    ARCH_IDS[name] = _lib.ARCH_USER
+    layers = len(convs) + 1
+
+    class UserNetwork(Network):
+        ARCH = name
+        CONVS, FC = convs, int(fc)
+
+        def __init__(self, conf):
+            super(UserNetwork, self).__init__(conf)
+            self.output = Placeholder('fc%d' % layers)
+
+    UserNetwork.__name__ = "%sNetwork" % name
+    return UserNetwork
 
 
 class NIPSNetwork(Network):

@@ -70,6 +70,7 @@ class DeviceRollout(object):
         self.graph_conv = [None, None]
         self.graph_b = None
         self.graph_multi = None                        # MULTI consecutive cycles (parity 0 first) in one launch
+        self.graph_multi_long = None                   # MULTI_LONG of them
         self.graph_ua = [None, None]                   # data parallel: update of the previous cycle + graph_a
         self.pending_update = False
         # data parallel: the cycle contains the gradient exchange
@@ -202,6 +203,8 @@ class DeviceRollout(object):
                     for parity in (0, 1):
                         self.graph_a[parity] = captured(lambda: cycle(parity, True))
                     self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
+                    if self.MULTI_LONG > self.MULTI:
+                        self.graph_multi_long = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI_LONG)])
                 return
             except Exception as exc:      # noqa: BLE001 -- whatever the runtime / RCCL raised: keep training, eagerly
                 logging.warning("gradient all-reduce could not be captured into the cycle graph (%s): issuing it eagerly", exc)
@@ -220,19 +223,27 @@ class DeviceRollout(object):
                 self.graph_b = captured(self._update)
             else:
                 self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
+                if self.MULTI_LONG > self.MULTI:
+                    self.graph_multi_long = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI_LONG)])
 
-    # cycles per launch of graph_multi (even: the ring parity is back at 0 afterwards)
+    # cycles per launch of graph_multi / graph_multi_long (even: the ring parity is back at 0 afterwards).  Measured at the
+    # headline configuration, cycles per launch 4 / 8 / 16 / 32: 643.5 / 645.6 / 648.6 / 648.1 k env-steps/s.
     MULTI = max(2, int(os.environ.get("PAAC_CYCLES_PER_LAUNCH", "4")) // 2 * 2)
+    MULTI_LONG = max(MULTI, int(os.environ.get("PAAC_CYCLES_PER_LONG_LAUNCH", "16")) // 2 * 2)
 
     def run_cycles(self, count):
-        """`count` cycles.  Single-process graph replay batches them MULTI per hipGraph launch where it can: the gap
-        between two graph launches on the GPU (about 8 us) is paid once per MULTI cycles instead of every cycle."""
+        """`count` cycles.  Graph replay batches them MULTI_LONG or MULTI per hipGraph launch where it can: the gap between
+        two graph launches on the GPU (about 8 us) is paid once per batch instead of every cycle."""
         count = int(count)
         while count > 0:
             if self.use_graph and (not self.phased or self.graph_exchange) and self.parity == 0 and count >= self.MULTI:
                 with torch.cuda.stream(self.stream):
                     if self.graph_a[0] is None:
                         self.capture()
+                    if self.graph_multi_long is not None and count >= self.MULTI_LONG:
+                        self.graph_multi_long.launch()
+                        count -= self.MULTI_LONG
+                        continue
                     self.graph_multi.launch()
                 count -= self.MULTI
             else:
@@ -295,6 +306,7 @@ class DeviceRollout(object):
 
     def close(self):
         for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b, self.graph_multi,
+                  self.graph_multi_long,
                   self.graph_ua[0], self.graph_ua[1]):
             if g is not None:
                 g.close()
@@ -302,6 +314,7 @@ class DeviceRollout(object):
         self.graph_conv = [None, None]
         self.graph_b = None
         self.graph_multi = None
+        self.graph_multi_long = None
         self.graph_ua = [None, None]
 
 
