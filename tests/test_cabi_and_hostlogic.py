@@ -229,3 +229,23 @@ def test_weight_init_ranges(arch, A):
     # two draws differ (unseeded default), a seeded draw repeats
     again = networks.initial_values(lay, np.random.RandomState(0))
     assert all(np.array_equal(vals[k], again[k]) for k in vals)
+
+
+def test_bench_roofline_ceiling_follows_the_recorded_instruction_mix():
+    """bench.py prices a contraction family against what it ran (products per multiply recorded by the library at launch
+    time): fp32 MFMA 157.3 TFLOP/s, dense bf16 2500 / products otherwise, harmonic over the bodies of a paired launch --
+    the conv tower at 1,536 rows (220 TFLOP/s fp32-equivalent, above the fp32-MFMA figure) stays below 1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    kind, bodies = bench.family_work("conv_tower", 1536, "NATURE", 4, 1686693)
+    assert kind == "flop" and len(bodies) == 2
+    peak = bench.mfma_ceiling(bodies, (3, 6))
+    assert 416.7 < peak < 833.4 and 220.0 / peak < 1.0 < 220.0 / bench.PEAK_FP32_MFMA_TFLOPS
+    assert abs(bench.mfma_ceiling([1.0], (1,)) - 157.3) < 1e-9 and abs(bench.mfma_ceiling([1.0], (6,)) - 2500.0 / 6) < 1e-9
+    # a paired launch is named for what the launcher paired, whatever the batch: conv2 + conv1 FLOPs, two bodies
+    kind, pair = bench.family_work("conv2_conv1_wgrad", 2560, "NATURE", 18, 1700000)
+    assert kind == "flop" and len(pair) == 2 and pair[0] == 2.0 * 2560 * 81 * 512 * 64 and pair[1] == 2.0 * 2560 * 400 * 256 * 32
+    assert bench.mfma_ceiling(pair, (1,)) is None             # a mix that does not match the bodies: no ceiling claimed
+    assert bench.family_work("clip_rmsprop", 0, "NATURE", 4, 1000)[0] == "byte"

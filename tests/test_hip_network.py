@@ -580,3 +580,37 @@ def test_backward_with_fused_returns_equals_separate_calls(arch, A, T, N):
         assert torch.equal(a, b)
     assert int(out[1][2].item()) == 1000 + B and int(out[1][3].item()) == 7 + T
     ctx.close()
+
+
+def test_profiling_hooks_name_the_launches_and_their_instruction_mix():
+    """paac_prof_read / paac_prof_read_mix: every launch of one update carries its family -- paired launches named for
+    what the launcher paired -- and the MFMA products per fp32 multiply of each contraction body (1 fp32 MFMA, 3 exact
+    bf16, 6 split bf16): what bench.py's roofline fractions are priced with."""
+    from paac_amd import hip_ops
+    B = 160
+    params, states, idx, y, adv = make_case("NATURE", 4, B + 32, seed=3)
+    ctx = hip_ops.Context(ARCH_ID["NATURE"], 4, max_batch=B + 32)
+    p = upload_params(ctx, params)
+    ctx.set_managed_weights(True)
+    ctx.pack_weights(p)
+    s = torch.from_numpy(states).cuda()
+    grad = torch.zeros(ctx.layout["total"], device="cuda")
+    probs = torch.zeros((32, 4), device="cuda")
+    ctx.prof_enable(True)
+    ctx.forward(p, s[:32], probs=probs)
+    ctx.train_forward_trunk(p, s)
+    ctx.loss_backward(p, s[:B], torch.from_numpy(idx[:B]).cuda(), torch.from_numpy(y[:B]).cuda(),
+                      torch.from_numpy(adv[:B]).cuda(), 0.02, grad, forward_done=True)
+    torch.cuda.synchronize()
+    recs = ctx.prof_read(with_mix=True)
+    ctx.prof_enable(False)
+    got = {(name, batch): mix for name, batch, ms, mix in recs}
+    assert all(ms > 0 for _, _, ms, _ in recs)
+    assert got[("conv_tower", 32)] == (3, 6) and got[("conv_tower", 192)] == (3, 6)
+    assert got[("fc_fwd", 32)] == (1,)                       # fc_heads_kernel: fp32 MFMA
+    assert got[("fc_fwd", 192)] == (6,) and got[("fc_dgrad", B)] == (6,)
+    assert got[("fc_conv3_wgrad", B)] == (1, 1) and got[("conv2_conv1_wgrad", B)] == (1, 3)
+    assert got[("dgrad_tower", B)] == (6,)
+    assert got[("heads_fwd", 32)] == () and ("conv3_wgrad", B) not in got and ("conv2_wgrad", B) not in got
+    assert ctx.prof_read() == []                              # the table was cleared
+    ctx.close()
