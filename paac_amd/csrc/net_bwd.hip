@@ -500,6 +500,13 @@ void default_tuning(paac_ctx* c) {
     c->tune[OP_CONV2_WGRAD][2] = Tune{kSplitBf16 + 3, 32, 2};
     c->tune[OP_CONV2_DGRAD][2] = Tune{10, 0, 0};
     c->tune[OP_CONV1_WGRAD][2] = Tune{kExactBf16 + 2, 64, 2};
+  } else {
+    // contexts sized for more than 2048 rows (the 8 x 128-environment shards at t_max 20: 2560 / 2688 rows): the conv
+    // weight gradients, TUNE_N=128 TUNE_T=20 TUNE_A=18 TUNE_OPS=6,8,10 tools/tune_gemm.py -- update 1135 -> 1040 us; the
+    // other ops keep the size heuristics there (the fc layer runs on gemm3.h, the conv data path on the tower kernels)
+    c->tune[OP_CONV3_WGRAD][2] = Tune{kSplitBf16 + 0, 48, 2};
+    c->tune[OP_CONV2_WGRAD][2] = Tune{kSplitBf16 + 1, 64, 2};
+    c->tune[OP_CONV1_WGRAD][2] = Tune{kExactBf16 + 2, 64, 2};
   }
   // classes 0 and 1: tools/tune_gemm.py on MI355X, 32 envs x t_max 5: acting batch 32 (class 0); training forward over
   // 192 rows and backward over 160 (class 1)

@@ -109,7 +109,9 @@ for cls, fn, label in ((batch_class(N), fwd_act, "act B=%d" % N), (batch_class(N
         print("(acting and training batch share class %d: tuning the training step only would override it)" % cls)
     base = time_graph(fn)
     print("%s: graph with the library's table %.1f us" % (label, base), flush=True)
-    ops = [o for o in OPS_ACTIVE if (o <= 3 or cls == 1)]
+    ops = [o for o in OPS_ACTIVE if (o <= 3 or cls >= 1)]
+    if os.environ.get("TUNE_OPS"):
+        ops = [o for o in ops if str(o) in os.environ["TUNE_OPS"].split(",")]
     for rnd in range(2):
         for op in ops:
             cur = best.get((op, cls), start[(op, cls)])      # start from the library's own table
