@@ -316,7 +316,7 @@ def test_act_step_equals_separate_calls(arch, A, N, managed):
 
 @pytest.mark.parametrize("N,A,multi", [(32, 4, False), (256, 4, False), (128, 18, False), (96, 6, False),
                                        (256, 4, True), (128, 18, True), (96, 6, True), (200, 3, True), (65, 2, True),
-                                       (32, 4, True)])
+                                       (32, 4, True), (100, 9, True)])      # 9 actions: the all-categories-at-once hop, J = 8
 def test_fused_sampler_env_step_equals_separate_calls(N, A, multi):
     """paac_sample_mt_synth_step (small and large-LDS variants: 256 environments x 4 actions = two-level table chase with
     one shift workgroup per environment; 128 x 18 = lane walk; multi: the group walks of the large shards spread over
