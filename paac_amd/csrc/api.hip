@@ -150,6 +150,17 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   for (int o = 0; o < OP_COUNT; ++o)
     for (int k = 0; k < 3; ++k) c->tune[o][k] = Tune{-1, 0, -1};
   default_tuning(c);
+  // diagnostic: PAAC_TUNE_OVERRIDE="op:class:cfg:ksplit:xcd[,...]" replaces entries of the table (the numbering of
+  // paac_debug_set_tuning), so that a whole bench.py run can be taken with another launch configuration
+  if (const char* ov = getenv("PAAC_TUNE_OVERRIDE")) {
+    int op, cls, cf, ks, xc, used = 0;
+    while (sscanf(ov, "%d:%d:%d:%d:%d%n", &op, &cls, &cf, &ks, &xc, &used) == 5) {
+      if (op >= 0 && op < OP_COUNT && cls >= 0 && cls < 3) c->tune[op][cls] = Tune{cf, ks, xc};
+      ov += used;
+      if (*ov != ',') break;
+      ++ov;
+    }
+  }
   const int64_t B = cfg->max_batch;
   const int A = cfg->num_actions;
   c->fc_splits_max = fc_splits_max();
