@@ -164,8 +164,10 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
 #endif
   // regions per sample: as many as keep the launch within about one round of the 256 CUs
   const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
-  // (measured: 8 regions of 4x2 beat 4 of 4x4 only while they fit half the CUs -- every workgroup streams all the weights)
-  int regions = (8 * batch <= 128) ? 8 : (4 * batch <= 288) ? 4 : (2 * batch <= 288) ? 2 : 1;
+  // (every workgroup streams all the weights, so more regions is more L2 traffic: at 32 rows 8 regions of 4x2 -- 256
+  // workgroups -- take 11.0 us as a launch of their own against 10.7 for 4 of 4x4, but the replayed cycle is 2 us shorter
+  // with them, 653 k against 648 k env-steps/s in two A/B pairs: the launch ramps and drains faster on all 256 CUs)
+  int regions = (8 * batch <= 256) ? 8 : (4 * batch <= 288) ? 4 : (2 * batch <= 288) ? 2 : 1;
   if (force == 1 || force == 2 || force == 4 || force == 8) regions = force;
   if (regions == 8) {
     if (keep) launch_tower_variant<TowerGeom<4, 2>, true>(a, s);
