@@ -11,9 +11,10 @@ RMSProp, on synthetic 84x84x4 uint8 frames generated on the device; value = env-
 slowest rank's wall time (weak scaling: 32 envs per GPU).  Workload at N=1 = BASELINE configs[1]
 (Breakout action set, Nature net, 32 envs, t_max=5).
 
-The timed region is repeated: `--windows` (default 5) consecutive windows of exactly K steps, each bracketed by
+The timed region is repeated: `--windows` (default 9) consecutive windows of exactly K steps, each bracketed by
 barrier + synchronize on both sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN window's
-(a 20-step window is 7 ms: one window alone is at the mercy of a clock ramp), all windows are listed in `windows_ms`.
+(a 20-step window is 5 ms and the clock is still ramping through the first two or three of them: one window alone is at
+the mercy of that ramp), all windows are listed in `windows_ms`.
 
 Extra objects on the JSON line:
   roofline     -- the kernel family with the largest share of the cycle, timed with HIP events attached to the
@@ -133,7 +134,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--windows", type=int, default=5, help="consecutive K-step windows; the median one is reported")
+    ap.add_argument("--windows", type=int, default=9, help="consecutive K-step windows; the median one is reported")
     ap.add_argument("--host-envs", action="store_true",
                     help="also time the host-plugin loop (PCIe-inclusive) on the same workload; reported beside value")
     a = ap.parse_args()
