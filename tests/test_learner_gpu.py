@@ -60,6 +60,7 @@ def oracle_cycles(args, params, env_creator, cycles, arch):
                                        np.float32(cyc["lr"]), args.alpha, 0.0, args.e)
         cyc["params"] = {k: v.copy() for k, v in p.items()}
         cyc["gnorm"] = gn
+        cyc["episodes"] = list(ro.finished_episodes)        # (global_step, reward, length) so far: paac.py:130-135
         outs.append(cyc)
     return outs
 
@@ -87,6 +88,13 @@ def test_host_loop_matches_oracle(game, arch, N, T):
     got = learner.network.get_parameters()
     for k, v in want[-1]["params"].items():
         assert np.abs(got[k] - v).max() < 2e-4, k
+    # the episode records (paac.py:130-135: global_step at the moment the per-environment loop reaches the finished
+    # environment, total unclipped reward, length) -- the host loop's bookkeeping is vectorised, the records must not move
+    import json, os
+    recs = [json.loads(l) for l in open(os.path.join(args.debugging_folder, "metrics.jsonl"))]
+    got_eps = [(r["global_step"], r["reward"], r["length"]) for r in recs if r["kind"] == "episode"]
+    want_eps = [(int(g), float(r), int(l)) for g, r, l in want[-1]["episodes"]]
+    assert len(want_eps) >= 3 and got_eps == want_eps
     # sampler stream position was written back to the global np.random like the reference leaves it
     rs = np.random.RandomState(args.test_seed)
     for c in range(cycles):
