@@ -1,4 +1,5 @@
 """In-tree build of libpaac_hip.so (gfx950 only).  Used by __graft_entry__.build() and `python -m paac_amd.build`."""
+import fcntl
 import os
 import subprocess
 import sys
@@ -21,9 +22,21 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True, extra_flags=(), lib_path=None, obj_suffix=""):
-    """extra_flags / lib_path / obj_suffix: diagnostic variants (e.g. -DPAAC_DMM_STAMPS into libpaac_hip_stamps.so)."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    """extra_flags / lib_path / obj_suffix: diagnostic variants (e.g. -DPAAC_DMM_STAMPS into libpaac_hip_stamps.so).
+    Safe to call from several processes at once (every torchrun rank calls it for a user architecture): the build runs
+    under an exclusive file lock next to the library, objects and library are written to temporary names and renamed into
+    place, so a rank that has already loaded the library never sees it rewritten under it."""
     lib = lib_path or LIB
+    with open(lib + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, extra_flags, lib, obj_suffix)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, extra_flags, lib, obj_suffix):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:
@@ -34,6 +47,19 @@ def build(force=False, verbose=True, extra_flags=(), lib_path=None, obj_suffix="
             jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o])
 
     def run(cmd):
+        # cmd ends in "-o <target>": produce <target>.tmp.<pid>, then rename over the target (atomic on one filesystem)
+        at = cmd.index("-o") + 1
+        target = cmd[at]
+        tmp = "%s.tmp.%d" % (target, os.getpid())
+        cmd = cmd[:at] + [tmp] + cmd[at + 1:]
+        try:
+            _run(cmd)
+            os.replace(tmp, target)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+
+    def _run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

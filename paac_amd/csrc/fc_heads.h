@@ -176,11 +176,13 @@ __device__ __forceinline__ void heads_from_partials(const float* __restrict__ pa
   for (int idx = tid; idx < n; idx += 256) {
     const int a = idx % (A + 1);
     float acc = (a < A) ? ba[a] : bc[0];
-    float v[32];
+    for (int t0 = 0; t0 < ntiles; t0 += 32) {          // fc widths beyond 512 (user architectures): 32 tiles at a time
+      float v[32];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];   // every load before the sum
+      for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t0 + t < ntiles ? t0 + t : 0) * n + idx];   // every load before the sum
 #pragma unroll
-    for (int t = 0; t < 32; ++t) acc += (t < ntiles) ? v[t] : 0.f;
+      for (int t = 0; t < 32; ++t) acc += (t0 + t < ntiles) ? v[t] : 0.f;
+    }
     lg_s[idx] = acc;
   }
   __syncthreads();
@@ -198,12 +200,24 @@ __device__ __forceinline__ void heads_partials_issue(const float* __restrict__ p
 #pragma unroll
   for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];
 }
-__device__ __forceinline__ void heads_from_issued(const float (&v)[32], const float bias, const int ntiles, const int B,
-                                                  const int A, float* lg_s, float* probs_lds, float* __restrict__ probs_out,
-                                                  float* __restrict__ values_out) {
+// (tiles beyond the 32 issued ones -- fc widths beyond 512 -- are read here, in the same order)
+__device__ __forceinline__ void heads_from_issued(const float (&v)[32], const float bias, const float* __restrict__ partial,
+                                                  const int ntiles, const int B, const int A, float* lg_s, float* probs_lds,
+                                                  float* __restrict__ probs_out, float* __restrict__ values_out) {
   float acc = bias;
 #pragma unroll
   for (int t = 0; t < 32; ++t) acc += (t < ntiles) ? v[t] : 0.f;
+  if (ntiles > 32) {
+    const int n = B * (A + 1);
+    const int idx = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
+    for (int t0 = 32; t0 < ntiles; t0 += 32) {
+      float w[32];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) w[t] = partial[(size_t)(t0 + t < ntiles ? t0 + t : 0) * n + idx];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) acc += (t0 + t < ntiles) ? w[t] : 0.f;
+    }
+  }
   if ((int)threadIdx.x < B * (A + 1)) lg_s[threadIdx.x] = acc;
   __syncthreads();
   heads_softmax_store(B, A, lg_s, probs_lds, nullptr, probs_out, values_out, nullptr, nullptr, nullptr);
@@ -236,11 +250,14 @@ static __global__ __launch_bounds__(256) void heads_finish_rows_kernel(const flo
   if (tid < n) {
     const int a = tid % (A + 1);
     float acc = (a < A) ? ba[a] : bc[0];
-    float v[32];
+    for (int t0 = 0; t0 < ntiles; t0 += 32) {
+      float v[32];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n_total + (size_t)row0 * (A + 1) + tid];
+      for (int t = 0; t < 32; ++t)
+        v[t] = partial[(size_t)(t0 + t < ntiles ? t0 + t : 0) * n_total + (size_t)row0 * (A + 1) + tid];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) acc += (t < ntiles) ? v[t] : 0.f;
+      for (int t = 0; t < 32; ++t) acc += (t0 + t < ntiles) ? v[t] : 0.f;
+    }
     lg_s[tid] = acc;
   }
   __syncthreads();

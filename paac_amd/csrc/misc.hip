@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
       // doubles, which need nothing but the state words -- the loads travel while those phases compute
       float pv[32], bias;
       heads_partials_issue(partial, ntiles, N * (A + 1), A, ba, bc, pv, bias);
-      auto finish_heads = [&]() { heads_from_issued(pv, bias, ntiles, N, A, lg_s, probs_sh, probs_out, values_out); };
+      auto finish_heads = [&]() { heads_from_issued(pv, bias, partial, ntiles, N, A, lg_s, probs_sh, probs_out, values_out); };
       sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, finish_heads);
     } else {
       heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,

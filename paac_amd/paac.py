@@ -535,12 +535,17 @@ class PAACLearner(ActorLearner):
         # the one learner), like the device loop -- lr anneals and max_global_steps ends on the global count
         world = self._world()
 
+        stock_rescale = type(self).rescale_reward is ActorLearner.rescale_reward
+
         def bookkeeping(t, step_rewards, step_overs):
             """paac.py:119-138 for one step, vectorised over the environments that did not end an episode; the finished
             ones are visited in index order with the global_step the reference's per-environment loop would show them."""
             masks[t] = 1.0 - step_overs
             total_episode_rewards[:] += step_rewards
-            rewards[t] = np.clip(step_rewards, -1.0, 1.0)          # rescale_reward, actor_learner.py:95-101
+            if stock_rescale:
+                rewards[t] = np.clip(step_rewards, -1.0, 1.0)      # rescale_reward, actor_learner.py:95-101
+            else:                                                  # a subclass's own rescale_reward, per reward like upstream
+                rewards[t] = [self.rescale_reward(r) for r in step_rewards]
             emulator_steps[:] += 1
             before = self.global_step
             self.global_step += N * world

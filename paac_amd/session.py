@@ -72,7 +72,9 @@ class Saver(object):
     def checkpoints(folder):
         import glob
         found = glob.glob(os.path.join(folder, "-*.npz")) + glob.glob(os.path.join(folder, "-*.index"))
-        return sorted((p for p in found if Saver.step_of(p) is not None), key=lambda p: (_step_of(p), p))
+        # oldest first; two containers saved at the same step (the format was switched between runs): the one written last
+        # is the newer checkpoint
+        return sorted((p for p in found if Saver.step_of(p) is not None), key=lambda p: (_step_of(p), os.path.getmtime(p), p))
 
     @staticmethod
     def step_of(path):
@@ -99,7 +101,6 @@ class Saver(object):
         if self.fmt == "tf":
             name = "-%d" % int(global_step)
             path = tf_bundle.write(os.path.join(folder, name), self.get_arrays())
-            tf_bundle.write_state_file(folder, name)
         else:
             path = os.path.join(folder, "-%d.npz" % int(global_step))
             tmp = os.path.join(folder, ".tmp-%d-%d.npz" % (int(global_step), os.getpid()))
@@ -111,6 +112,11 @@ class Saver(object):
         for p in self.checkpoints(folder)[:-self.max_to_keep]:
             if p != path:
                 self._remove(p)
+        if self.fmt == "tf":
+            # every bundle still on disk, oldest first, the new one last: a tf.train.Saver resuming from this folder keeps
+            # tracking (and pruning) the older ones
+            kept = [os.path.basename(p)[:-len(".index")] for p in self.checkpoints(folder) if p.endswith(".index") and p != path]
+            tf_bundle.write_state_file(folder, name, kept + [name])
         return path
 
     def restore(self, session, path):

@@ -358,9 +358,12 @@ def readable(prefix):
         return False
 
 
-def write_state_file(folder, prefix_name):
-    """The `checkpoint` text file tf.train.latest_checkpoint reads (networks.py:125)."""
+def write_state_file(folder, prefix_name, all_prefix_names=None):
+    """The `checkpoint` text file tf.train.latest_checkpoint reads (networks.py:125): the newest prefix, then every prefix
+    the saver still keeps (oldest first), one `all_model_checkpoint_paths` line each like tf.train.Saver writes them."""
     tmp = os.path.join(folder, ".checkpoint.tmp-%d" % os.getpid())
     with open(tmp, "w") as f:
-        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (prefix_name, prefix_name))
+        f.write('model_checkpoint_path: "%s"\n' % prefix_name)
+        for name in (all_prefix_names or [prefix_name]):
+            f.write('all_model_checkpoint_paths: "%s"\n' % name)
     os.replace(tmp, os.path.join(folder, "checkpoint"))

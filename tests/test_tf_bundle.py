@@ -112,3 +112,27 @@ def test_saver_writes_and_resumes_from_either_container(tmp_path):
     assert np.array_equal(got["x/w"], state["x/w"])
     os.truncate(tmp_path / "-30.data-00000-of-00001", 8)                      # a torn newest checkpoint is skipped
     assert Saver.latest_checkpoint(str(tmp_path)).endswith("-20.npz")
+
+
+def test_state_file_lists_every_kept_bundle_and_same_step_ties_go_to_the_newer_container(tmp_path):
+    """tf.train.Saver's `checkpoint` state file names every checkpoint still on disk (oldest first), so a reference saver
+    resuming from the folder keeps pruning them; and after switching --checkpoint_format at an unchanged step the container
+    written last is the one resumed from."""
+    import time
+    from paac_amd.session import Saver
+    state = {"x/w": np.zeros((2, 2), dtype=np.float32)}
+    s = Saver(lambda: state, lambda d: None, max_to_keep=2, fmt="tf")
+    for step in (5, 6, 7):
+        s.save(None, str(tmp_path), step)
+    lines = open(tmp_path / "checkpoint").read().splitlines()
+    assert lines == ['model_checkpoint_path: "-7"', 'all_model_checkpoint_paths: "-6"', 'all_model_checkpoint_paths: "-7"']
+    assert not os.path.exists(tmp_path / "-5.index")
+    # same step, other container, written later
+    state["x/w"] = state["x/w"] + 3
+    time.sleep(0.02)
+    Saver(lambda: state, lambda d: None, max_to_keep=5, fmt="npz").save(None, str(tmp_path), 7)
+    assert Saver.latest_checkpoint(str(tmp_path)).endswith("-7.npz")
+    time.sleep(0.02)
+    state["x/w"] = state["x/w"] + 3
+    s.save(None, str(tmp_path), 7)
+    assert Saver.latest_checkpoint(str(tmp_path)).endswith("-7.index")
