@@ -84,11 +84,13 @@ def family_work(name, batch, arch, A, P, raw=False):
     # kernels around the network: batch = environments per launch (nstep_returns: N*T elements)
     OBS, RAW = 28224.0, 2 * 33600.0
     if name in ("env_step", "sample_env_step"):      # read the stacks, write the shifted stacks (+ the sampler's [N,A] probs)
-        if raw and name == "env_step":                # path B: the step WRITES the two raw 210x160 screens
-            return "byte", batch * (RAW + 24.0)
+        if raw:                                       # path B: the step WRITES the two raw 210x160 screens
+            return "byte", batch * (RAW + (4.0 * A if name == "sample_env_step" else 0.0) + 24.0)
         return "byte", batch * (2 * OBS + (4.0 * A if name == "sample_env_step" else 0.0) + 24.0)
-    if name == "preprocess_stack":                    # two raw screens in, stack in, stack out
-        return "byte", batch * (RAW + 2 * OBS)
+    if name == "preprocess_stack":
+        # SURVEY 8(d), row-granular gather: the 84 source rows (of 210) the nearest resize keeps, 160 B each, of both
+        # screens; the stack in and the stack out
+        return "byte", batch * (2 * 84 * 160.0 + 2 * OBS)
     if name in ("sample_mt", "sample_philox"):
         return "byte", batch * (4.0 * A + 4.0) + (2496.0 * 2 if name == "sample_mt" else 0.0)
     if name == "nstep_returns":                       # rewards, masks, values in; y, adv out

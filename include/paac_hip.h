@@ -109,6 +109,21 @@ int paac_train_forward(paac_ctx* ctx, const float* params, const uint8_t* states
  * [batch, batch + N) of this forward (paac.py:140-142: the bootstrap observations appended to the rollout rows). */
 int paac_train_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, paac_stream_t stream);
 
+/* An update without a training forward.  Weights are frozen inside a cycle (paac.py:99-165), so the T acting forwards of a
+ * rollout have already computed the activations the update's forward (paac.py:163-165) would recompute.
+ * paac_keep_next_forward(ctx, r): the NEXT acting forward on this ctx (paac_forward / paac_act_step_mt of at most 256 rows,
+ * three-conv network, managed weights) also leaves its rows' conv1 / conv2 / conv3 outputs and fc activations at rows
+ * [r, r + batch) of the ctx's training activation set (one shot; r = -1 cancels).
+ * paac_bootstrap_forward_trunk: an acting-shaped forward (conv tower + fc, no heads) of the N bootstrap observations
+ * (paac.py:140-142), kept at rows [train_row, train_row + batch) -- after the T acting steps were kept at rows t*N and
+ * this call at T*N, paac_loss_backward[_returns](forward_done = 1) runs on the kept rows exactly as after
+ * paac_train_forward_trunk (v_boot == NULL: bootstrap values from rows [batch, batch + N)).  Same mathematics as the
+ * reference's second session.run over the same observations; the values differ from a recomputed forward only by the
+ * summation order of the kernels involved. */
+int paac_keep_next_forward(paac_ctx* ctx, int train_row);
+int paac_bootstrap_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, int train_row,
+                                 paac_stream_t stream);
+
 /* One whole acting step of the device-resident loop in three launches (paac.py:104-127 for N <= 64 environments with
  * the reference's numpy sampler): policy forward on `states` (conv tower, fc with the head contractions in its epilogue),
  * then ONE launch that finishes the heads (bias, softmax; probabilities and values also written to probs_out [N,A] /
@@ -116,13 +131,16 @@ int paac_train_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* 
  * environment on the MT19937 state, advanced in place) and steps the synthetic environments like paac_synth_step
  * (stack_out = shifted stacks with the new frame, stack_out2 (nullable) = a second copy of them; rewards / masks /
  * episode bookkeeping).
+ * raw_scratch (nullable, [N,2,210,160] u8): path B like paac_synth_step's -- the step launch writes the step's raw screen
+ * pairs there instead of shifting the stacks, and one more launch (paac_preprocess_stack's kernel: max of the two screens,
+ * PIL-nearest resize, history push, reset on terminal) builds stack_out / stack_out2 from them: four launches.
  * Requires N <= PAAC_ACT_STEP_MAX_ENVS and N*(A-1) <= 1024. */
 #define PAAC_ACT_STEP_MAX_ENVS 64
 int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
                      uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
                      uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
-                     void* finished, paac_stream_t stream);
+                     void* finished, uint8_t* raw_scratch, paac_stream_t stream);
 
 /* Conv-weight packing.  The Nature conv layers run as one fused launch that reads the conv weights pre-split into bf16
  * planes (an internal copy owned by the ctx).  By default every paac_forward* / paac_train_forward / paac_loss_backward
@@ -262,14 +280,16 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
  * left to the library and lent to every call of the same (N, A) in one stream order.  With it the large shards (more than
  * 64 environments or 1024 draws) spread the sampler's walk over several workgroups of the launch (same actions, same
  * stream position; 49 -> 14 us at 256 environments x 4 actions, 41 -> 24 us at 128 x 18); without it one workgroup walks
- * all environments. */
+ * all environments.
+ * raw_scratch (nullable, [N,2,210,160] u8): path B -- the launch's other workgroups write the step's raw screen pairs there
+ * instead of shifting, and the preprocess launch (max, PIL-nearest resize, history push) follows, like paac_synth_step's. */
 #define PAAC_FUSED_SAMPLE_MAX_DRAWS 2304
 int64_t paac_walk_scratch_bytes(int N, int A);
 int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
                               uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
-                              void* walk_scratch, int64_t walk_scratch_bytes, paac_stream_t stream);
+                              void* walk_scratch, int64_t walk_scratch_bytes, uint8_t* raw_scratch, paac_stream_t stream);
 
 /* hipGraph helpers: capture every launch issued on `stream` between begin/end, replay with launch. */
 int paac_graph_begin(paac_stream_t stream);

@@ -54,6 +54,8 @@ _SIGNATURES = {
                                     c_uint32, c_void_p, c_void_p]),
     "paac_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "paac_train_forward_trunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "paac_keep_next_forward": (c_int, [c_void_p, c_int]),
+    "paac_bootstrap_forward_trunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "paac_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "paac_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -80,11 +82,11 @@ _SIGNATURES = {
                                 c_void_p]),
     "paac_act_step_mt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                  c_uint32, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "paac_walk_scratch_bytes": (c_int64, [c_int, c_int]),
     "paac_sample_mt_synth_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_uint32, c_int, c_uint32, c_void_p,
                                           c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_int64, c_void_p]),
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "paac_forward_sample_synth_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_void_p,
                                                c_uint64, c_uint32, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -187,6 +187,10 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   PAAC_CHECK_HIP(hipMalloc(&c->wslab, (size_t)c->wslab_floats * sizeof(float)));
   PAAC_CHECK_HIP(hipMalloc(&c->partials, 8192 * sizeof(float)));
   PAAC_CHECK_HIP(hipMemset(c->partials, 0, 8192 * sizeof(float)));
+  PAAC_CHECK_HIP(hipMalloc(&c->zeros, (size_t)(c->spec.fc > 1024 ? c->spec.fc : 1024) * sizeof(float)));
+  PAAC_CHECK_HIP(hipMemset(c->zeros, 0, (size_t)(c->spec.fc > 1024 ? c->spec.fc : 1024) * sizeof(float)));
+  c->keep_row = -1;
+  c->heads_pending_h = 0;
   {
     const char* v = getenv("PAAC_TOWER");
     c->tower_on = (cfg->arch == PAAC_ARCH_NATURE) && !(v && *v && atoi(v) == 0);
@@ -222,7 +226,7 @@ int paac_destroy(paac_ctx* c) {
   }
   for (int i = 0; i < 3; ++i)
     if (c->dact[i]) (void)hipFree(c->dact[i]);
-  float* bufs[] = {c->dh, c->wslab, c->partials, c->dl_buf};
+  float* bufs[] = {c->dh, c->wslab, c->partials, c->dl_buf, c->zeros};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (c->tower_pack) (void)hipFree(c->tower_pack);
@@ -286,6 +290,25 @@ int paac_train_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* 
   return 0;
 }
 
+int paac_keep_next_forward(paac_ctx* ctx, int train_row) {
+  PAAC_REQUIRE(ctx, "paac_keep_next_forward: null ctx");
+  PAAC_REQUIRE(train_row >= -1 && train_row < ctx->max_batch, "paac_keep_next_forward: row %d outside [-1, max_batch=%d)",
+               train_row, ctx->max_batch);
+  ctx->keep_row = train_row;
+  return 0;
+}
+
+int paac_bootstrap_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, int train_row,
+                                 paac_stream_t stream) {
+  PAAC_REQUIRE(ctx && params && states, "paac_bootstrap_forward_trunk: null argument");
+  PAAC_REQUIRE(batch > 0 && train_row >= 0 && train_row + batch <= ctx->max_batch,
+               "paac_bootstrap_forward_trunk: rows [%d, %d) outside max_batch=%d", train_row, train_row + batch, ctx->max_batch);
+  const int rc = launch_bootstrap_trunk(ctx, params, states, batch, train_row, (hipStream_t)stream);
+  if (rc) return rc;
+  PAAC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int paac_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,
                         float* values, uint64_t seed, const uint64_t* step_base_dev, uint64_t step_offset,
                         uint32_t env_offset, int32_t* actions, paac_stream_t stream) {
@@ -321,7 +344,7 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
                      uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
                      uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
-                     void* finished, paac_stream_t stream) {
+                     void* finished, uint8_t* raw_scratch, paac_stream_t stream) {
   PAAC_REQUIRE(ctx && params && states && mt_state && actions && probs_out && values_out && stack_out && rewards_out &&
                masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS,
@@ -336,7 +359,7 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
   if (rc) return rc;
   rc = launch_sample_env_step_heads(partial, ntiles, ba, bc, probs_out, values_out, ctx->cfg.num_actions, mt_state, actions,
                                     env_seed, env_offset, batch, terminal_threshold, step_base_dev, step_offset, states,
-                                    stack_out, stack_out2, rewards_out, masks_out, ep_reward, ep_len, finished,
+                                    stack_out, stack_out2, rewards_out, masks_out, ep_reward, ep_len, finished, raw_scratch,
                                     (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());

@@ -120,6 +120,13 @@ struct paac_ctx {
   // paac_train_forward_trunk stopped the training forward (ws[1]) after the fc layer's split-K slabs: rows covered and
   // slab count; the next backward finishes the heads (fused into its first launch where it can)
   int heads_pending_rows, heads_pending_splits;
+  // paac_keep_next_forward: the next acting forward (ws[0] routes of the conv tower + fc_heads_kernel) also leaves its rows'
+  // activations -- conv1 / conv2 / conv3 outputs and the fc activations -- at rows [keep_row, keep_row + batch) of the
+  // TRAINING activation set, so that an update over rows the acting steps have already computed needs no training forward
+  // (weights are frozen inside a cycle).  -1 = off (one shot: the forward that honours it resets it).
+  int keep_row;
+  int heads_pending_h;             // 1: the pending "slab" holds finished fc activations (bias + ReLU applied), one split
+  float* zeros;                    // max(H) zero floats (the bias of heads that read finished activations)
   float* dl_buf;                   // [max_batch][kDlStride] per-row head gradients + loss terms (heads.h)
   int fc_splits_max;
   // conv tower (csrc/tower.h, Nature only): conv weights pre-split into bf16 planes in MFMA operand order
@@ -207,13 +214,15 @@ int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t
                                void* finished, hipStream_t s);
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s);
 int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s);
+int launch_bootstrap_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, int train_row, hipStream_t s);
 int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, const float** partial,
                          int* ntiles, const float** ba, const float** bc, hipStream_t s);
 int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,
                                  float* values_out, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                                  uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
                                  const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
-                                 float* masks, float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s);
+                                 float* masks, float* ep_reward, int32_t* ep_len, void* finished, uint8_t* raw_scratch,
+                                 hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s,
                     const paac_returns* ret = nullptr);

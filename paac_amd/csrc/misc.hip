@@ -854,64 +854,77 @@ __device__ __forceinline__ uint32_t gray601(uint32_t r, uint32_t g, uint32_t b) 
   return (r * 19595u + g * 38470u + b * 7471u + 32768u) >> 16;
 }
 
-constexpr int PRE_ROWS_PER_BAND = 12;  // 3 iterations of 4 waves
+constexpr int PRE_ROWS_PER_BAND = 12;  // 84 output rows = PRE_BANDS (7) bands of 12
 
-// grid (N, 7), 256 threads.  Each wave stages the two source rows of one output row in LDS with
-// coalesced dword loads, then gathers the 84 nearest columns and emits the shifted 4-channel stack
-// as one dword per pixel: out = (old >> 8) | (new << 24)  (channel 0 = oldest = lowest byte).
+// grid (N, 7), 256 threads: a workgroup builds 12 output rows of one environment in ONE pass.
+//   stage   the 2 x 12 source rows the band's output rows map to (PIL nearest: kRowLut) go to LDS with one 16-byte load per
+//           thread (gray: 240 of the 256 threads, 3,840 B; RGB: three loads per thread, 11,520 B) -- whole 160- / 480-byte
+//           rows, so every 128-byte line fetched is used in full;
+//   gather  after the one barrier, thread q < 252 owns output quad (row q / 21, pixels 4 (q % 21) ..+3): four column
+//           gathers per frame from LDS (kColLut), max of the two frames (atari_emulator.py:72: max before resize == after),
+//           and the 4-deep history shift on whole pixels: out = (old >> 8) | (new << 24)  (channel 0 = oldest = lowest
+//           byte; environment.py:66-71) -- one 16-byte load of the old stack (requested before the staging loads, so it
+//           travels with them) and one 16-byte store per thread.
+// In-place (stack_out == stack_in) is safe: a thread reads and writes the same 16 bytes.
 template <bool RGB>
 __global__ __launch_bounds__(256) void preprocess_stack_kernel(const uint8_t* __restrict__ raw, int N,
-                                                               const uint32_t* __restrict__ stack_in,
-                                                               uint32_t* __restrict__ stack_out,
+                                                               const uint32_t* stack_in, uint32_t* stack_out,
                                                                uint32_t* __restrict__ stack_out2,
                                                                const uint8_t* __restrict__ push_mask,
                                                                const uint8_t* __restrict__ reset_mask,
                                                                const float* __restrict__ reset_when_zero) {
-  constexpr int ROWB = RGB ? 480 : 160;  // bytes per source row
-  constexpr int ROWD = ROWB / 4;
-  __shared__ uint32_t rows[4][2][ROWD];
+  constexpr int ROWB = RGB ? 480 : 160;           // bytes per source row
+  constexpr int VPR = ROWB / 16;                  // 16-byte vectors per source row
+  constexpr int SRC_VEC = PRE_ROWS_PER_BAND * 2 * VPR;      // 240 (gray) / 720 (RGB)
+  constexpr int QPR = OBS_W / 4;                  // 21 output quads per row
+  __shared__ uint4 rows[SRC_VEC];                 // [band row][frame][ROWB bytes]
   const int e = blockIdx.x;
   const int band = blockIdx.y;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
   const bool push = push_mask ? (push_mask[e] != 0) : true;
   bool reset = reset_mask ? (reset_mask[e] != 0) : false;
   if (reset_when_zero) reset = reset || (reset_when_zero[e] == 0.0f);
-  const uint8_t* fr = raw + (long)e * 2 * PAAC_RAW_H * ROWB;
-  for (int it = 0; it < PRE_ROWS_PER_BAND / 4; ++it) {
-    const int y = band * PRE_ROWS_PER_BAND + it * 4 + wave;
-    const int ry = kRowLut.v[y];
-    if (push) {
-      for (int f = 0; f < 2; ++f) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(fr + ((long)f * PAAC_RAW_H + ry) * ROWB);
-        for (int d = lane; d < ROWD; d += 64) rows[wave][f][d] = src[d];
-      }
+  const bool has_quad = tid < PRE_ROWS_PER_BAND * QPR;       // 252
+  const int qy = tid / QPR, qx = tid - qy * QPR;
+  const long quad = ((long)e * OBS_PIX + (band * PRE_ROWS_PER_BAND + qy) * OBS_W) / 4 + qx;
+  uint4 old = make_uint4(0u, 0u, 0u, 0u);
+  if (has_quad) old = reinterpret_cast<const uint4*>(stack_in)[quad];
+  if (push) {
+    const uint8_t* fr = raw + (long)e * 2 * PAAC_RAW_H * ROWB;
+#pragma unroll
+    for (int v = tid; v < SRC_VEC; v += 256) {
+      const int r = v / (2 * VPR), rem = v - r * (2 * VPR);
+      const int f = rem / VPR, c = rem - f * VPR;
+      const int ry = kRowLut.v[band * PRE_ROWS_PER_BAND + r];
+      rows[v] = *reinterpret_cast<const uint4*>(fr + ((long)f * PAAC_RAW_H + ry) * ROWB + c * 16);
     }
-    __syncthreads();
-    for (int x = lane; x < 84; x += 64) {
-      const long pix = (long)e * OBS_PIX + y * 84 + x;
-      const uint32_t old = stack_in[pix];
-      uint32_t outv = old;
-      if (push) {
-        const int cx = kColLut.v[x];
-        uint32_t v0, v1;
-        if (RGB) {
-          const uint8_t* b0 = reinterpret_cast<const uint8_t*>(rows[wave][0]) + cx * 3;
-          const uint8_t* b1 = reinterpret_cast<const uint8_t*>(rows[wave][1]) + cx * 3;
-          v0 = gray601(b0[0], b0[1], b0[2]);
-          v1 = gray601(b1[0], b1[1], b1[2]);
-        } else {
-          v0 = reinterpret_cast<const uint8_t*>(rows[wave][0])[cx];
-          v1 = reinterpret_cast<const uint8_t*>(rows[wave][1])[cx];
-        }
-        const uint32_t nv = v0 > v1 ? v0 : v1;                 // atari_emulator.py:72 (max before resize == after)
-        outv = ((reset ? 0u : old) >> 8) | (nv << 24);          // environment.py:66-71
-      }
-      stack_out[pix] = outv;
-      if (stack_out2) stack_out2[pix] = outv;
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  if (!has_quad) return;
+  uint4 outv = old;
+  if (push) {
+    const uint8_t* r0 = reinterpret_cast<const uint8_t*>(rows) + (qy * 2) * ROWB;
+    const uint8_t* r1 = r0 + ROWB;
+    const uint32_t o[4] = {old.x, old.y, old.z, old.w};
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cx = kColLut.v[qx * 4 + k];
+      uint32_t v0, v1;
+      if (RGB) {
+        v0 = gray601(r0[cx * 3], r0[cx * 3 + 1], r0[cx * 3 + 2]);
+        v1 = gray601(r1[cx * 3], r1[cx * 3 + 1], r1[cx * 3 + 2]);
+      } else {
+        v0 = r0[cx];
+        v1 = r1[cx];
+      }
+      const uint32_t nv = v0 > v1 ? v0 : v1;
+      w[k] = ((reset ? 0u : o[k]) >> 8) | (nv << 24);
+    }
+    outv = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  reinterpret_cast<uint4*>(stack_out)[quad] = outv;
+  if (stack_out2) reinterpret_cast<uint4*>(stack_out2)[quad] = outv;
 }
 
 // =============================================================================================
@@ -920,33 +933,18 @@ __global__ __launch_bounds__(256) void preprocess_stack_kernel(const uint8_t* __
 __global__ __launch_bounds__(256) void synth_step_a_kernel(uint64_t seed, uint32_t env_offset, int N,
                                                            const int32_t* __restrict__ actions, uint32_t thresh,
                                                            const uint64_t* __restrict__ step_base, uint64_t step_off,
-                                                           int force_reset, const uint32_t* __restrict__ stack_in,
-                                                           uint32_t* __restrict__ stack_out,
+                                                           int force_reset, const uint32_t* stack_in,
+                                                           uint32_t* stack_out,
                                                            uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                            float* masks_out, float* ep_reward, int32_t* ep_len,
                                                            FinishedRing* fin) {
   const int e = blockIdx.x;
   const int band = blockIdx.y;
   const uint64_t id = force_reset ? 0ull : (step_base ? *step_base : 0ull) + step_off + 1ull;
-  const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
-  bool reset = force_reset != 0;
-  if (!force_reset) {
-    reset = lowbias32(key ^ 0x3C6EF372u) < thresh;
-    if (band == 0 && threadIdx.x == 0)
-      synth_bookkeep(key, e, actions, thresh, rewards_out, masks_out, ep_reward, ep_len, fin);
-  }
-  constexpr int PIX_PER_BAND = OBS_PIX / PRE_BANDS;  // 1008
-  for (int i = threadIdx.x; i < PIX_PER_BAND; i += 256) {
-    const int p = band * PIX_PER_BAND + i;
-    const int y = p / 84, x = p - y * 84;
-    const uint32_t w = synth_word(key, (uint32_t)(y * 21 + (x >> 2)));
-    const uint32_t nv = (w >> (8 * (x & 3))) & 255u;
-    const long pix = (long)e * OBS_PIX + p;
-    const uint32_t old = reset ? 0u : stack_in[pix];
-    const uint32_t outv = (old >> 8) | (nv << 24);
-    stack_out[pix] = outv;
-    if (stack_out2) stack_out2[pix] = outv;
-  }
+  if (!force_reset && band == 0 && threadIdx.x == 0)
+    synth_bookkeep(synth_key(seed, env_offset + (uint32_t)e, id), e, actions, thresh, rewards_out, masks_out, ep_reward, ep_len,
+                   fin);
+  synth_shift_band(seed, env_offset, id, thresh, e * PRE_BANDS + band, stack_in, stack_out, stack_out2, force_reset != 0);
 }
 
 // Path A with the numpy-parity sampler folded in: workgroup 0 runs the (inherently serial) MT19937 sampler and then
@@ -965,7 +963,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
                                                               uint32_t* __restrict__ stack_out,
                                                               uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                               float* masks_out, float* ep_reward, int32_t* ep_len,
-                                                              FinishedRing* fin, const MultiWalk mw) {
+                                                              FinishedRing* fin, const MultiWalk mw,
+                                                              uint32_t* __restrict__ raw) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   const int samplers = mw.W > 0 ? mw.W : 1;          // sampler workgroups in front of the shift workgroups
   if ((int)blockIdx.x < samplers) {
@@ -993,10 +992,13 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     // every workgroup of this launch reserves the sampler's LDS, so a CU holds one: the (environment, band) units are dealt
     // over as many shift workgroups as fit beside the sampler workgroups in ONE round of the CUs
     const int nshift = (int)gridDim.x - samplers;
-    for (int u = (int)blockIdx.x - samplers; u < N * PRE_BANDS; u += nshift)
-      synth_shift_band(seed, env_offset, id, thresh, u, stack_in, stack_out, stack_out2);
+    for (int u = (int)blockIdx.x - samplers; u < N * PRE_BANDS; u += nshift) {
+      if (raw) synth_raw_unit(seed, env_offset, id, u, raw);       // path B: the step's raw screen pair instead of the shift
+      else synth_shift_band(seed, env_offset, id, thresh, u, stack_in, stack_out, stack_out2);
+    }
   } else {
-    synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - samplers, stack_in, stack_out, stack_out2);
+    if (raw) synth_raw_unit(seed, env_offset, id, (int)blockIdx.x - samplers, raw);
+    else synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - samplers, stack_in, stack_out, stack_out2);
   }
 }
 
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
                                                                uint32_t* __restrict__ stack_out,
                                                                uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                                float* masks_out, float* ep_reward, int32_t* ep_len,
-                                                               FinishedRing* fin) {
+                                                               FinishedRing* fin, uint32_t* __restrict__ raw) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   if (blockIdx.x == 0) {
     __shared__ int16_t act_s[kFcHeadsMaxRows];
@@ -1048,7 +1050,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
       synth_bookkeep_hashed(hr5, term0, e0, act_s[e0], ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
     return;
   }
-  synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
+  if (raw) synth_raw_unit(seed, env_offset, id, (int)blockIdx.x - 1, raw);     // path B: the preprocess launch follows
+  else synth_shift_band(seed, env_offset, id, thresh, (int)blockIdx.x - 1, stack_in, stack_out, stack_out2);
 }
 
 // Path B, stage 1: generate the two raw 210x160 gray frames of this step + bookkeeping.
@@ -1066,8 +1069,10 @@ __global__ __launch_bounds__(256) void synth_raw_kernel(uint64_t seed, uint32_t 
     synth_bookkeep(key, e, actions, thresh, rewards_out, masks_out, ep_reward, ep_len, fin);
   const uint32_t rkey = key ^ 0x5bd1e995u;
   constexpr int WORDS = 2 * PAAC_RAW_H * PAAC_RAW_W / 4;  // 16800
-  for (int w = blockIdx.y * 256 + threadIdx.x; w < WORDS; w += 256 * gridDim.y)
-    raw[(long)e * WORDS + w] = synth_word(rkey, (uint32_t)w);
+  uint4* out = reinterpret_cast<uint4*>(raw + (long)e * WORDS);
+  for (int q = blockIdx.y * 256 + threadIdx.x; q < WORDS / 4; q += 256 * gridDim.y)     // one 16-byte store per 4 words
+    out[q] = make_uint4(synth_word(rkey, (uint32_t)(4 * q)), synth_word(rkey, (uint32_t)(4 * q + 1)),
+                        synth_word(rkey, (uint32_t)(4 * q + 2)), synth_word(rkey, (uint32_t)(4 * q + 3)));
 }
 
 __global__ void fill_f32_kernel(float* p, float v, int n) {
@@ -1530,15 +1535,31 @@ static void fill_pack_spec(const paac_ctx* ctx, PackSpec* pk, int* fc_tiles, int
   }
 }
 
+// Path B, second launch of a step: the observation stacks from the raw screen pairs the step launch has just written
+// (max of the two screens, PIL-nearest resize, history push; environments whose mask is 0 -- terminal -- restart from an
+// empty history, like paac_synth_step's path B).
+static void launch_preprocess_after_step(const uint8_t* raw_scratch, int N, const uint8_t* stack_in, uint8_t* stack_out,
+                                         uint8_t* stack_out2, const float* masks, hipStream_t s) {
+  ProfScope ps(g_prof_ctx, F_PREPROCESS_STACK, N, s);
+  launch_k(preprocess_stack_kernel<false>, dim3(N, PRE_BANDS), dim3(256), s, PROF_WHOLE, raw_scratch, N,
+           (const uint32_t*)stack_in, (uint32_t*)stack_out, (uint32_t*)stack_out2, (const uint8_t*)nullptr,
+           (const uint8_t*)nullptr, masks);
+}
+
 int launch_sample_env_step_heads(const float* partial, int ntiles, const float* ba, const float* bc, float* probs_out,
                                  float* values_out, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed,
                                  uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
                                  const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
-                                 float* masks, float* ep_reward, int32_t* ep_len, void* finished, hipStream_t s) {
-  ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, s);
-  launch_k(synth_step_a_mth_kernel, dim3(1 + N * PRE_BANDS), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
-           values_out, A, mt_state, actions, seed, env_offset, N, thresh, step_base, step_off, (const uint32_t*)stack_in,
-           (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished);
+                                 float* masks, float* ep_reward, int32_t* ep_len, void* finished, uint8_t* raw_scratch,
+                                 hipStream_t s) {
+  {
+    ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, s);
+    launch_k(synth_step_a_mth_kernel, dim3(1 + N * PRE_BANDS), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
+             values_out, A, mt_state, actions, seed, env_offset, N, thresh, step_base, step_off, (const uint32_t*)stack_in,
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished,
+             (uint32_t*)raw_scratch);
+  }
+  if (raw_scratch) launch_preprocess_after_step(raw_scratch, N, stack_in, stack_out, stack_out2, masks, s);
   return 0;
 }
 
@@ -1720,12 +1741,13 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
                               uint32_t env_offset, int N, uint32_t terminal_threshold, const uint64_t* step_base_dev,
                               uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
-                              void* walk_scratch, int64_t walk_scratch_bytes, paac_stream_t stream) {
+                              void* walk_scratch, int64_t walk_scratch_bytes, uint8_t* raw_scratch, paac_stream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
   PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D2, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
                "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D2);
   PAAC_REQUIRE(probs && mt_state && actions && stack_in && stack_out && rewards_out && masks_out && ep_reward && ep_len,
                "paac_sample_mt_synth_step: null argument");
+  {
   ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, (hipStream_t)stream);
   // small shards: the small-LDS sampler, one shift workgroup per band; beyond 1024 draws or 64 environments (where the
   // two-level chase needs the large first-hit table): the large-LDS sampler, one shift workgroup per environment
@@ -1750,11 +1772,15 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
   if (large)
     launch_k(synth_step_a_mt_kernel<2>, dim3(samplers + nshift), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
              mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
-             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw);
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
+             (uint32_t*)raw_scratch);
   else
     launch_k(synth_step_a_mt_kernel<1>, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
              actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
-             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw);
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
+             (uint32_t*)raw_scratch);
+  }
+  if (raw_scratch) launch_preprocess_after_step(raw_scratch, N, stack_in, stack_out, stack_out2, masks_out, (hipStream_t)stream);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -210,10 +210,12 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   if (do_fc && fused_heads) {
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
     const int rows = ctx->heads_pending_rows;
+    // (rows kept by the acting forwards hold finished fc activations: one "slab", zero bias -- fmaxf(h + 0, 0) == h)
     launch_heads_train<NT::H>(A, dim3(batch), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * NT::H,
-                              params + L.offset[i_wf + 1], wa, params + L.offset[i_wa + 1], wc, params + L.offset[i_wc + 1], A,
+                              ctx->heads_pending_h ? (const float*)ctx->zeros : params + L.offset[i_wf + 1], wa, params + L.offset[i_wa + 1], wc, params + L.offset[i_wc + 1], A,
                               batch, W.h, W.logits, W.probs, W.values, actions, y, adv, beta, ctx->dh, ctx->dl_buf, rtl);
     ctx->heads_pending_rows = 0;
+    ctx->heads_pending_h = 0;
   } else if (do_fc) {
     ProfScope ps(ctx, F_HEADS_BWD, batch, s);
     launch_heads_bwd<NT::H>(A, dim3(batch + NT::H / 32 + 1), s, (const float*)W.probs, (const float*)W.values, actions, y,

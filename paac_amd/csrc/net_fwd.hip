@@ -142,8 +142,10 @@ static void launch_tower_variant(const TowerArgs& a, hipStream_t s) {
 
 // keep = also write the fp32 conv1 / conv2 activations (the backward pass and the debug read-back need them)
 // packed3: conv3's output goes out in fc_heads_kernel's A-fragment order (acting rows that nothing else reads)
+// keepW / keep_row: the rows are ALSO kept in another activation set (the training set) at row offset keep_row -- fp32 conv1
+// / conv2 outputs and a plain-row copy of conv3's -- while the fragment-order conv3 output for the fc kernel goes to W
 static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const uint8_t* states, int batch, bool keep,
-                         bool packed3, hipStream_t s) {
+                         bool packed3, hipStream_t s, Workspace* keepW = nullptr, int keep_row = 0) {
   const paac_layout& L = ctx->layout;
   TowerArgs a;
   a.states = states;
@@ -159,6 +161,13 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
   a.act3 = W.act[2];
   a.batch = batch;
   a.act3_packed = packed3 ? 1 : 0;
+  a.act3_rows = nullptr;
+  if (keepW) {
+    keep = true;
+    a.act1 = keepW->act[0] + (size_t)keep_row * 400 * NatureNet::C1;
+    a.act2 = keepW->act[1] + (size_t)keep_row * 81 * NatureNet::C2;
+    a.act3_rows = keepW->act[2] + (size_t)keep_row * NatureNet::FLAT;
+  }
 #ifdef PAAC_DMM_STAMPS
   a.stamps = g_tower_stamps;
 #endif
@@ -213,6 +222,12 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
 
   bool tower = false;
   if constexpr (NT::NCONV == 3) tower = ctx->tower_on != 0;
+  // paac_keep_next_forward (one shot): this acting forward's rows are also kept in the training activation set
+  int keep_row = -1;
+  if (wsi == 0) {
+    keep_row = ctx->keep_row;
+    ctx->keep_row = -1;
+  }
   const bool keep_acts = wsi == 1 || !ctx->managed_weights;          // fp32 conv activations / h kept for backward and read-back
   const bool small_tail = batch <= kFcHeadsMaxRows && !ph.enabled && !st.enabled;   // fc + head partials kernel (fc_heads.h)
   // conv3 -> fc hand-off in the fc kernel's fragment order: rows are padded to 16 inside the activation buffer (max_batch
@@ -220,7 +235,17 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   // ... and acting batches of up to 256 rows (the 128- / 256-environment shards) take the same fc kernel, finished by a
   // few workgroups (heads_finish_rows_kernel) instead of split-K slabs + a per-row heads launch
   const bool mid_tail = !small_tail && tower && !keep_acts && wsi == 0 && batch <= kFcHeadsMidRows && !ph.enabled &&
-                        !st.enabled && !defer_heads && !trunk_only;
+                        !st.enabled && !trunk_only;
+  Workspace* keepW = nullptr;
+  if (keep_row >= 0) {
+    if (!(tower && !keep_acts && (small_tail || mid_tail) && keep_row + batch <= ctx->max_batch)) {
+      set_error("paac_keep_next_forward: rows [%d, %d) cannot be kept -- needs the three-conv network's tower, managed weights, an "
+                "acting forward of at most %d rows and keep_row + batch <= max_batch (%d)", keep_row, keep_row + batch,
+                kFcHeadsMidRows, ctx->max_batch);
+      return -1;
+    }
+    keepW = &ctx->ws[1];
+  }
   // (measured at 128 rows: fragment-order hand-off tower 16.5 + fc 8.7 us, plain rows 15.2 + 10.4)
   const bool packed3 = tower && (small_tail || mid_tail) && !keep_acts;
   if (!ctx->managed_weights && (tower || batch <= kFcHeadsMaxRows)) launch_pack_weights(ctx, params, s);
@@ -228,7 +253,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
     prof_mix(3);       // conv1: u8 pixels x weights split into 3 bf16 terms
     prof_mix(6);       // conv2, conv3: six-product split-bf16
-    launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s);
+    launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s, keepW, keep_row < 0 ? 0 : keep_row);
   }
   if (!tower) {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
@@ -257,24 +282,27 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     constexpr int NTILES = NT::H / 16;
     float* partial = W.fc_slab;      // [NTILES][batch][A + 1]: fits the split-K slab buffer
     const bool keep_h = keep_acts;
+    // kept rows: the finished fc activations (bias + ReLU applied) go where the training forward's fc slabs would be
+    float* h_keep = keepW ? keepW->fc_slab + (size_t)keep_row * NT::H : nullptr;
     {
       ProfScope ps(ctx, F_FC_FWD, batch, s);
       prof_mix(1);     // fp32 MFMA
       constexpr int NW = (NT::FLAT / 16) % 7 == 0 ? 7 : 9;      // waves per workgroup: divides the K groups evenly
       if (packed3)
         launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, true>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,
-                 last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, (float*)nullptr);
+                 last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, h_keep);
       else
         launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, false>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,
                  last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial,
                  keep_h ? W.h : (float*)nullptr);
     }
+    if (defer_heads) return 0;       // the caller's launch finishes the heads (or, for bootstrap rows, the backward's)
     if (mid_tail) {
       ProfScope ps(ctx, F_HEADS_FWD, batch, s);
       const int rpw = 256 / (A + 1);
       launch_k(heads_finish_rows_kernel, dim3((batch + rpw - 1) / rpw), dim3(256), s, PROF_WHOLE, (const float*)partial, NTILES,
                batch, A, rpw, ba, bc, W.logits, W.probs, W.values, logits, probs, values);
-    } else if (!defer_heads) {
+    } else {
       ProfScope ps(ctx, F_HEADS_FWD, batch, s);
       launch_k(heads_finish_kernel, dim3(1), dim3(256), s, PROF_WHOLE, (const float*)partial, NTILES, batch, A, ba, bc,
                W.logits, W.probs, W.values, logits, probs, values);
@@ -297,6 +325,7 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   if (trunk_only && wsi == 1) {      // the backward's first launch finishes the heads (heads.h: heads_train_kernel)
     ctx->heads_pending_rows = batch;
     ctx->heads_pending_splits = splits;
+    ctx->heads_pending_h = 0;
     return 0;
   }
   {
@@ -346,8 +375,10 @@ int launch_deferred_heads(paac_ctx* ctx, const float* params, hipStream_t s) {
   SynthStepArgs st;
   memset(&st, 0, sizeof(st));
   const int A = ctx->cfg.num_actions, H = ctx->spec.fc;
-  const float *bf = params + L.offset[nt - 5], *wa = params + L.offset[nt - 4], *ba = params + L.offset[nt - 3],
-              *wc = params + L.offset[nt - 2], *bc = params + L.offset[nt - 1];
+  // (rows kept by acting forwards hold finished fc activations: a zero bias and one "slab" reproduce them exactly)
+  const float *bf = ctx->heads_pending_h ? ctx->zeros : params + L.offset[nt - 5], *wa = params + L.offset[nt - 4],
+              *ba = params + L.offset[nt - 3], *wc = params + L.offset[nt - 2], *bc = params + L.offset[nt - 1];
+  ctx->heads_pending_h = 0;
   ProfScope ps(ctx, F_HEADS_FWD, rows, s);
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     launch_heads_fwd<NatureNet::H>(A, dim3(rows), s, (const float*)W.fc_slab, ctx->heads_pending_splits, (long)rows * H, bf, wa,
@@ -376,6 +407,28 @@ int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* stat
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
   return forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+}
+
+// Acting-shaped forward of the N bootstrap observations whose rows complete a training set the acting steps have kept
+// (paac_keep_next_forward): conv tower + fc, rows kept at [train_row, train_row + batch); no heads -- the backward's first
+// launch takes the bootstrap values from the kept fc activations like it does after a trunk-only training forward.
+int launch_bootstrap_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, int train_row, hipStream_t s) {
+  PhiloxArgs ph;
+  memset(&ph, 0, sizeof(ph));
+  SynthStepArgs st;
+  memset(&st, 0, sizeof(st));
+  ctx->keep_row = train_row;
+  int rc;
+  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
+    rc = forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+  else
+    rc = forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+  ctx->keep_row = -1;
+  if (rc) return rc;
+  ctx->heads_pending_rows = train_row + batch;
+  ctx->heads_pending_splits = 1;
+  ctx->heads_pending_h = 1;
+  return 0;
 }
 
 int launch_forward_sample(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, float* probs,

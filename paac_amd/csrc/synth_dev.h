@@ -68,26 +68,43 @@ __device__ __forceinline__ bool synth_bookkeep(uint32_t key, int e, const int32_
 }
 
 // Frame shift of one (env, band) unit of path A: push the step's new 84x84 plane into the 4-deep history
-// (one dword = the 4 channels of a pixel).  unit = env * PRE_BANDS + band; 256 threads.
+// (one dword = the 4 channels of a pixel).  unit = env * PRE_BANDS + band; 256 threads, 252 of them own one quad of four
+// pixels each: ONE generator word is the quad's four new bytes, one 16-byte load and one 16-byte store per thread.
 __device__ __forceinline__ void synth_shift_band(uint64_t seed, uint32_t env_offset, uint64_t id, uint32_t thresh, int unit,
                                                  const uint32_t* __restrict__ stack_in, uint32_t* __restrict__ stack_out,
-                                                 uint32_t* __restrict__ stack_out2 = nullptr) {
+                                                 uint32_t* __restrict__ stack_out2 = nullptr,
+                                                 const bool force_reset = false) {
   const int e = unit / PRE_BANDS;
   const int band = unit % PRE_BANDS;
   const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
-  const bool reset = lowbias32(key ^ 0x3C6EF372u) < thresh;
-  constexpr int PIX_PER_BAND = OBS_PIX / PRE_BANDS;  // 1008
-  for (int i = threadIdx.x; i < PIX_PER_BAND; i += 256) {
-    const int p = band * PIX_PER_BAND + i;
-    const int y = p / 84, x = p - y * 84;
-    const uint32_t w = synth_word(key, (uint32_t)(y * 21 + (x >> 2)));
-    const uint32_t nv = (w >> (8 * (x & 3))) & 255u;
-    const long pix = (long)e * OBS_PIX + p;
-    const uint32_t old = reset ? 0u : stack_in[pix];
-    const uint32_t outv = (old >> 8) | (nv << 24);
-    stack_out[pix] = outv;
-    if (stack_out2) stack_out2[pix] = outv;      // second copy of the new stacks (the observation ring's wrap-around slot)
-  }
+  const bool reset = force_reset || lowbias32(key ^ 0x3C6EF372u) < thresh;
+  constexpr int QUADS_PER_BAND = OBS_PIX / PRE_BANDS / 4;  // 252: 12 rows of 21 quads
+  const int i = threadIdx.x;
+  if (i >= QUADS_PER_BAND) return;
+  const int q = band * QUADS_PER_BAND + i;                 // = y * 21 + (x >> 2): the generator's word index
+  const long quad = (long)e * (OBS_PIX / 4) + q;
+  uint4 old = make_uint4(0u, 0u, 0u, 0u);
+  if (!reset) old = reinterpret_cast<const uint4*>(stack_in)[quad];
+  const uint32_t w = synth_word(key, (uint32_t)q);
+  const uint4 outv = make_uint4((old.x >> 8) | ((w & 255u) << 24), (old.y >> 8) | (((w >> 8) & 255u) << 24),
+                                (old.z >> 8) | (((w >> 16) & 255u) << 24), (old.w >> 8) | ((w >> 24) << 24));
+  reinterpret_cast<uint4*>(stack_out)[quad] = outv;
+  if (stack_out2) reinterpret_cast<uint4*>(stack_out2)[quad] = outv;   // second copy (the observation ring's wrap-around slot)
+}
+
+// Path B: one of PRE_BANDS parts of environment e's raw 2 x 210 x 160 gray screen pair for step `id` (16,800 generator
+// words = 4,200 16-byte stores per environment, 600 per unit).  unit = env * PRE_BANDS + part; 256 threads.
+__device__ __forceinline__ void synth_raw_unit(uint64_t seed, uint32_t env_offset, uint64_t id, int unit,
+                                               uint32_t* __restrict__ raw) {
+  const int e = unit / PRE_BANDS;
+  const int part = unit % PRE_BANDS;
+  const uint32_t rkey = synth_key(seed, env_offset + (uint32_t)e, id) ^ 0x5bd1e995u;
+  constexpr int WORDS = 2 * PAAC_RAW_H * PAAC_RAW_W / 4;   // 16800
+  constexpr int PER = WORDS / 4 / PRE_BANDS;               // 600
+  uint4* out = reinterpret_cast<uint4*>(raw + (long)e * WORDS);
+  for (int q = part * PER + (int)threadIdx.x; q < (part + 1) * PER; q += 256)
+    out[q] = make_uint4(synth_word(rkey, (uint32_t)(4 * q)), synth_word(rkey, (uint32_t)(4 * q + 1)),
+                        synth_word(rkey, (uint32_t)(4 * q + 2)), synth_word(rkey, (uint32_t)(4 * q + 3)));
 }
 
 }  // namespace paac

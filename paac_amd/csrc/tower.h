@@ -43,6 +43,8 @@ struct TowerArgs {
   float* act3;                             // [B,7,7,64]   fp32 = the fc layer's input rows (flatten keeps HWC, networks.py:6-9)
   int act3_packed;                         // 1: act3 is written in fc_heads_kernel's A-fragment order instead:
                                            //    [row tile b/16][K group k/16][(k%16)/4 * 16 + b%16][k%4], k = (y*7 + x)*64 + c
+  float* act3_rows;                        // nullable: a second, plain-row copy of conv3's output (acting rows kept for the
+                                           // update: the fc weight gradient reads rows, the fc kernel fragments)
   int batch;
 #ifdef PAAC_DMM_STAMPS
   unsigned long long* stamps;               // diagnostic build only: 12 x u64 per wave
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
           *reinterpret_cast<f32x4*>(p.act3 + ((((size_t)(b >> 4) * (3136 / 16) + (k0 >> 4)) * 64 + ((k0 >> 2) & 3) * 16 + (b & 15)) << 2)) = v;
         else
           *reinterpret_cast<f32x4*>(p.act3 + (size_t)b * 3136 + k0) = v;
+        if (p.act3_rows) *reinterpret_cast<f32x4*>(p.act3_rows + (size_t)b * 3136 + k0) = v;
       }
     }
   }

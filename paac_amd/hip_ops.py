@@ -195,11 +195,25 @@ class Context(object):
                                               _ptr(gnorm_out, torch.float32, 1, "gnorm_out", True), _stream()),
                    "paac_clip_rmsprop")
 
+    def keep_next_forward(self, train_row):
+        """The next acting forward also leaves its rows' activations at rows [train_row, train_row + batch) of the training
+        activation set (include/paac_hip.h: paac_keep_next_forward); -1 cancels."""
+        _lib.check(self.lib.paac_keep_next_forward(self.handle, int(train_row)), "paac_keep_next_forward")
+
+    def bootstrap_forward_trunk(self, params, states, train_row):
+        """Acting-shaped forward (conv tower + fc) of the bootstrap observations, kept at rows [train_row, ...) of the training
+        set the acting steps have filled: the next loss_backward[_returns](forward_done=True) needs no training forward."""
+        B = self._check_states(states)
+        _lib.check(self.lib.paac_bootstrap_forward_trunk(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+                                                         _ptr(states, torch.uint8, B * 28224, "states"), B, int(train_row), _stream()),
+                   "paac_bootstrap_forward_trunk")
+
     def act_step_mt(self, params, states, mt_state, actions, probs_out, values_out, env_seed, env_offset,
                     terminal_threshold, step_base_dev, step_offset, stack_out, rewards_out, masks_out, ep_reward, ep_len,
-                    finished=None, stack_out2=None):
+                    finished=None, stack_out2=None, raw_scratch=None):
         """One acting step in three launches: policy forward, then heads finish + numpy-parity sampler + synthetic
-        environment step in one (include/paac_hip.h: paac_act_step_mt)."""
+        environment step in one (include/paac_hip.h: paac_act_step_mt).  raw_scratch ([N,2,210,160] u8): path B -- the
+        step launch writes the raw screen pairs, a fourth launch (max, PIL-nearest resize, history push) builds the stacks."""
         N, A = self._check_states(states), self.num_actions
         if N > ACT_STEP_MAX_ENVS or N * (A - 1) > ACT_STEP_MAX_DRAWS:
             raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS, ACT_STEP_MAX_DRAWS))
@@ -219,7 +233,8 @@ class Context(object):
             _ptr(rewards_out, torch.float32, N, "rewards_out"),
             _ptr(masks_out, torch.float32, N, "masks_out"), _ptr(ep_reward, torch.float32, N, "ep_reward"),
             _ptr(ep_len, torch.int32, N, "ep_len"),
-            ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0), _stream()),
+            ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0),
+            _ptr(raw_scratch, torch.uint8, N * 2 * RAW_H * RAW_W, "raw_scratch", True), _stream()),
             "paac_act_step_mt")
 
     def pack_weights(self, params):
@@ -409,6 +424,7 @@ def synth_step(seed, env_offset, actions, terminal_threshold, step_base_dev, ste
 FUSED_SAMPLE_MAX_DRAWS = 2304
 ACT_STEP_MAX_DRAWS = 1024
 ACT_STEP_MAX_ENVS = 64
+KEEP_FORWARD_MAX_ROWS = 256      # paac_keep_next_forward: acting forwards of up to this many rows (csrc/fc_heads.h)
 
 
 def walk_scratch(N, A, device):
@@ -419,7 +435,7 @@ def walk_scratch(N, A, device):
 
 def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_threshold, step_base_dev, step_offset,
                          stack_in, stack_out, rewards_out, masks_out, ep_reward, ep_len, finished=None, stack_out2=None,
-                         walk_scratch=None):
+                         walk_scratch=None, raw_scratch=None):
     N, A = probs.shape
     if N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
         raise ValueError("fused sampler+env step supports N*(A-1) <= %d" % FUSED_SAMPLE_MAX_DRAWS)
@@ -438,7 +454,8 @@ def sample_mt_synth_step(probs, mt_state, actions, seed, env_offset, terminal_th
         _ptr(ep_reward, torch.float32, N, "ep_reward"), _ptr(ep_len, torch.int32, N, "ep_len"),
         ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0),
         ctypes.c_void_p(walk_scratch.data_ptr()) if walk_scratch is not None else ctypes.c_void_p(0),
-        int(walk_scratch.numel()) if walk_scratch is not None else 0, _stream()),
+        int(walk_scratch.numel()) if walk_scratch is not None else 0,
+        _ptr(raw_scratch, torch.uint8, N * 2 * RAW_H * RAW_W, "raw_scratch", True), _stream()),
         "paac_sample_mt_synth_step")
 
 

@@ -90,6 +90,14 @@ class DeviceRollout(object):
         self.side_group = parallel.side_group() if (self.phased and not self.single_exchange) else None    # collective call
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
+        # The update needs no forward of its own: weights are frozen inside a cycle, so the T acting forwards have already
+        # computed the activations paac.py:163-165 recomputes (TensorFlow's feed/fetch model forces that second pass; nothing
+        # else does).  Acting step t keeps its rows at [t*N, (t+1)*N) of the training activation set, the N bootstrap
+        # observations (paac.py:140-142) run as one acting-shaped forward into rows [T*N, (T+1)*N), and the backward starts
+        # from there.  PAAC_REUSE_ACTING=0 restores the recomputed training forward (both routes are tested).
+        self.reuse_acting = (os.environ.get("PAAC_REUSE_ACTING", "1") != "0" and sampler == "numpy"
+                             and len(L.network.layout["tensors"]) == 12 and os.environ.get("PAAC_TOWER", "1") != "0"
+                             and N <= hip_ops.KEEP_FORWARD_MAX_ROWS)
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
         torch.cuda.synchronize(dev)
 
@@ -107,16 +115,21 @@ class DeviceRollout(object):
         L, T, N = self.L, self.T, self.N
         params = L.network.params
         st = [self.states[self._slot(parity, t)] for t in range(T + 1)]
+        keep = self.reuse_acting
         for t in range(T):
+            if keep:
+                L.ctx.keep_next_forward(t * N)
             # the ring wraps after an odd cycle: its last step also writes slot 0 (the next even cycle's first slot)
             wrap = self.states[0] if (parity == 1 and t == T - 1) else None
-            fused = self.sampler == "numpy" and self.raw is None and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS
+            # (path B -- self.raw -- rides the same fused launches: they write the raw screen pairs instead of shifting the
+            # stacks and the preprocess launch follows)
+            fused = self.sampler == "numpy" and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS
             if fused and N <= hip_ops.ACT_STEP_MAX_ENVS and N * (self.A - 1) <= hip_ops.ACT_STEP_MAX_DRAWS:
                 # the whole step in three launches: conv tower, fc + head partials, heads finish + sampler + env step
                 L.ctx.act_step_mt(params, st[t], self.mt_state, self.actions[t], self.probs, self.values[t],
                                   self.env_spec["seed"], self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
                                   st[t + 1], self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
-                                  stack_out2=wrap)
+                                  stack_out2=wrap, raw_scratch=self.raw)
                 continue
             if fused:
                 # numpy-parity sampler and env step in one launch (the frame shift does not need the action)
@@ -124,7 +137,8 @@ class DeviceRollout(object):
                 hip_ops.sample_mt_synth_step(self.probs, self.mt_state, self.actions[t], self.env_spec["seed"],
                                              self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
                                              st[t], st[t + 1], self.rewards[t], self.masks[t], self.ep_reward,
-                                             self.ep_len, self.finished, stack_out2=wrap, walk_scratch=self.walk_scratch)
+                                             self.ep_len, self.finished, stack_out2=wrap, walk_scratch=self.walk_scratch,
+                                             raw_scratch=self.raw)
                 continue
             if self.sampler == "numpy":
                 L.ctx.forward(params, st[t], probs=self.probs, values=self.values[t])
@@ -148,7 +162,10 @@ class DeviceRollout(object):
         # training forward over the T*N rollout rows with the N bootstrap observations appended (paac.py:140-142)
         # (the forward stops after the fc layer: the heads of the rollout rows AND the value head of the bootstrap rows are
         # finished inside the backward's first launch)
-        L.ctx.train_forward_trunk(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4))
+        if keep:
+            L.ctx.bootstrap_forward_trunk(params, st[T], T * N)
+        else:
+            L.ctx.train_forward_trunk(params, self.states[parity * T:(parity + 1) * T + 1].view((T + 1) * N, 84, 84, 4))
         # n-step returns + global_step/lr schedule + frame counter (paac.py:127,144-156) ride in the backward's first
         # launch.  One process: whole backward here, with the slab reduction of the conv weight gradients left to the norm
         # pass of the optimizer step that follows (phase 3: one launch less); data parallel: the complete gradient

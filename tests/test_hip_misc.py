@@ -140,16 +140,20 @@ def test_lr_step():
         assert lr.item() == np.float32(oroll.get_lr(step, 0.0224, 80000000))
 
 
+@pytest.mark.parametrize("N", [5, 256])          # 256: BASELINE configs[2] ("large-batch preprocess/HBM path")
 @pytest.mark.parametrize("rgb", [False, True])
-def test_preprocess_stack_bit_exact(rgb):
+def test_preprocess_stack_bit_exact(rgb, N):
+    """atari_emulator.py:69-75 (max of the two screens, nearest resize) + environment.py:58-75 (history push) for N
+    environments in one launch, push / reset masks on: every byte against the oracle's PIL-pinned restatement."""
     from paac_amd import hip_ops
-    rs = np.random.RandomState(11)
-    N = 5
+    rs = np.random.RandomState(11 + N)
     shape = (N, 2, 210, 160, 3) if rgb else (N, 2, 210, 160)
     raw = rs.randint(0, 256, shape).astype(np.uint8)
     stack = rs.randint(0, 256, (N, 84, 84, 4)).astype(np.uint8)
-    push = np.array([1, 1, 0, 1, 1], dtype=np.uint8)
-    reset = np.array([0, 1, 0, 0, 0], dtype=np.uint8)
+    push = (rs.rand(N) < 0.8).astype(np.uint8)
+    reset = (rs.rand(N) < 0.3).astype(np.uint8)
+    push[:5] = [1, 1, 0, 1, 1]
+    reset[:5] = [0, 1, 0, 0, 0]
     out = torch.zeros((N, 84, 84, 4), dtype=torch.uint8, device="cuda")
     hip_ops.preprocess_stack(dev(raw), dev(stack), out, dev(push), dev(reset))
     want = np.empty_like(stack)

@@ -135,26 +135,32 @@ def test_device_loop_matches_host_loop(raw_frames, use_graph):
     ro.close()
 
 
-@pytest.mark.parametrize("game,N,T,cycles,arch", [
-    ("breakout", 32, 5, 3, "NATURE"),      # BASELINE configs[1] (the headline): fused numpy-parity sampler + env-step launch
-    ("qbert", 32, 5, 2, "NATURE"),         # BASELINE configs[3] per-GPU shard (A=6)
-    ("seaquest", 128, 20, 1, "NATURE"),    # BASELINE configs[4] per-GPU shard (A=18): 2176 draws -> the large-LDS sampler, lane walk
-    ("breakout", 256, 5, 1, "NATURE"),     # BASELINE configs[2]: 256 environments -> the large-LDS sampler, two-level table chase
+@pytest.mark.parametrize("game,N,T,cycles,arch,raw", [
+    ("breakout", 32, 5, 3, "NATURE", False),      # BASELINE configs[1] (the headline): fused numpy-parity sampler + env-step launch
+    ("qbert", 32, 5, 2, "NATURE", False),         # BASELINE configs[3] per-GPU shard (A=6)
+    ("seaquest", 128, 20, 1, "NATURE", False),    # BASELINE configs[4] per-GPU shard (A=18): 2176 draws -> the large-LDS sampler, lane walk
+    ("breakout", 256, 5, 1, "NATURE", False),     # BASELINE configs[2]: 256 environments -> the large-LDS sampler, two-level table chase
     # ragged shapes (tools/stress_shapes.py runs more of them): one environment and one step; odd counts on both
     # networks; one past the 64-environment limit of the three-launch acting step
-    ("breakout", 1, 1, 2, "NATURE"),
-    ("qbert", 7, 5, 2, "NIPS"),
-    ("seaquest", 5, 7, 2, "NATURE"),
-    ("breakout", 65, 5, 1, "NATURE"),
+    ("breakout", 1, 1, 2, "NATURE", False),
+    ("qbert", 7, 5, 2, "NIPS", False),
+    ("seaquest", 5, 7, 2, "NATURE", False),
+    ("breakout", 65, 5, 1, "NATURE", False),
+    # path B (raw 210x160 screen pairs written by the step launch, max / PIL-nearest resize / history push by the preprocess
+    # launch): BASELINE configs[2]'s "large-batch preprocess/HBM path" at its 256 environments, the headline shape, a ragged one
+    ("breakout", 256, 5, 1, "NATURE", True),
+    ("breakout", 32, 5, 2, "NATURE", True),
+    ("qbert", 9, 3, 2, "NATURE", True),
 ])
-def test_device_loop_matches_oracle(game, N, T, cycles, arch):
+def test_device_loop_matches_oracle(game, N, T, cycles, arch, raw):
     """The device-resident cycle (hipGraph replay, numpy-parity sampler) against the CPU restatement of paac.py:99-165
     on the same synthetic environments and np.random stream: observations and actions bit for bit, values / returns /
     weights within the float tolerance."""
     from paac_amd import hip_ops
     from paac_amd.paac import DeviceRollout
     args = make_args(game=game, arch=arch, emulator_counts=N, emulator_workers=0, max_local_steps=T,
-                     max_global_steps=1 << 40, synthetic_terminal_p=0.05, sampler="numpy", test_seed=11)
+                     max_global_steps=1 << 40, synthetic_terminal_p=0.05, sampler="numpy", test_seed=11,
+                     synthetic_raw_frames=raw)
     learner, params, env_creator = build_learner(args)
     A = args.num_actions
     assert N * (A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS       # every BASELINE shard runs the fused sampler + env step
