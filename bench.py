@@ -210,6 +210,28 @@ def main():
             ro.capture()                # recording the graphs executes nothing: kept out of the timed region even at W = 0
     ro.run_cycles(a.warmup)
     ro.synchronize()
+    # data parallel: the replicas must hold bit-identical weights and optimizer slots -- compared (checksums, MIN / MAX over
+    # ranks) after the warm-up, where the exchanged gradient of the last warm-up update is compared too, and again after the
+    # timed windows; a mismatch is reported in the line and ends the run non-zero on every rank
+    replicas_identical = None
+    replica_error = None
+
+    def check_replicas(with_grad):
+        nonlocal replicas_identical, replica_error
+        if not ro.phased or replica_error is not None:
+            return
+        from paac_amd import parallel
+        try:
+            if with_grad and a.warmup > 0:
+                ro.check_replicas("grad")
+            ro.check_replicas("weights")
+            replicas_identical = True
+        except parallel.ReplicaMismatch as exc:
+            replicas_identical = False
+            replica_error = str(exc)
+            print("bench.py: %s" % exc, file=sys.stderr, flush=True)
+
+    check_replicas(True)
     windows = []
     for _ in range(max(1, a.windows)):
         barrier()
@@ -223,6 +245,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         windows.append(dt)
+    check_replicas(False)
     elapsed = sorted(windows)[len(windows) // 2]          # the median window
     value = world * N * T * a.steps / elapsed
     finite = bool(torch.isfinite(learner.network.params).all().item())
@@ -360,6 +383,9 @@ def main():
                            "RCCL sum all-reduce of the flat gradient per update in two pieces (PAAC_ALLREDUCE=split: the fc/heads "
                            "tail overlaps the conv backward)"))},
             "finite_params": finite,
+            "replicas_identical": replicas_identical,       # null with one process (nothing to compare)
+            "exchange": {"mode": ro.exchange_mode, "requested": os.environ.get("PAAC_ALLREDUCE", "graph"),
+                         "fallback_reason": ro.exchange_fallback, "replica_error": replica_error},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_plugin_loop": host_loop, "kernels": kernels,
         }
         import ctypes
@@ -372,6 +398,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if replica_error is not None:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,11 @@ class DeviceRollout(object):
         self.single_exchange = mode != "split"
         self.graph_exchange = self.phased and mode == "graph" and use_graph and parallel.backend() == "nccl"
         self.side_group = parallel.side_group() if (self.phased and not self.single_exchange) else None    # collective call
+        # what the exchange really runs as (graph mode may fall back: capture()); PAAC_VERIFY_EXCHANGE=0 skips the check of
+        # the replayed collective against the eager one
+        self.exchange_mode = "none" if not self.phased else ("split" if not self.single_exchange else "single")
+        self.exchange_fallback = None
+        self.verify_exchange = os.environ.get("PAAC_VERIFY_EXCHANGE", "1") != "0"
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
         # The update needs no forward of its own: weights are frozen inside a cycle, so the T acting forwards have already
@@ -213,6 +218,7 @@ class DeviceRollout(object):
         if self.graph_exchange:
             # the communicator must exist before a capture can record its collective: one eager all-reduce of a scratch
             # word first; a capture that raises leaves the eager form in charge
+            reason = None
             try:
                 parallel.allreduce_sum_(torch.zeros(1, dtype=torch.float32, device=self.L.torch_device))
                 torch.cuda.synchronize(self.L.torch_device)
@@ -222,11 +228,26 @@ class DeviceRollout(object):
                     self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
                     if self.MULTI_LONG > self.MULTI:
                         self.graph_multi_long = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI_LONG)])
-                return
             except Exception as exc:      # noqa: BLE001 -- whatever the runtime / RCCL raised: keep training, eagerly
-                logging.warning("gradient all-reduce could not be captured into the cycle graph (%s): issuing it eagerly", exc)
-                self.close()
-                self.graph_exchange = False
+                reason = "the capture raised: %s" % (exc,)
+            # every rank takes the same route: one that kept replaying graphs beside a peer issuing its collectives eagerly
+            # would pair the wrong calls
+            if not parallel.all_ranks(reason is None, self.L.torch_device):
+                reason = reason or "the capture failed on another rank"
+            elif self.verify_exchange:
+                # ... and before the replayed collective is trusted: the same cycle, from the same state, once with the
+                # eager exchange and once replayed -- the exchanged gradients must agree bit for bit, on every rank
+                with torch.cuda.stream(self.stream):
+                    same = self._replay_matches_eager()
+                if not parallel.all_ranks(same, self.L.torch_device):
+                    reason = "a replayed cycle's exchanged gradient differs from the eager exchange's" + ("" if not same else " on another rank")
+            if reason is None:
+                self.exchange_mode = "graph"
+                return
+            logging.warning("PAAC_ALLREDUCE=graph not used (%s): the all-reduce is issued eagerly between two graph launches", reason)
+            self.exchange_fallback = reason
+            self.close()
+            self.graph_exchange = False
         with torch.cuda.stream(self.stream):
             for parity in (0, 1):
                 self.graph_a[parity] = captured(lambda: cycle(parity, not self.phased))
@@ -243,6 +264,58 @@ class DeviceRollout(object):
                 if self.MULTI_LONG > self.MULTI:
                     self.graph_multi_long = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI_LONG)])
 
+    # -- trust, but verify: the captured exchange ---------------------------------------------------------
+    def _cycle_state(self):
+        """Every tensor one cycle reads and writes (the rollout's and the learner's): a snapshot of them is a restart point."""
+        L = self.L
+        ts = [self.states, self.actions, self.values, self.rewards, self.masks, self.probs, self.y, self.adv, self.ep_reward,
+              self.ep_len, self.finished, self.tick, self.global_step_dev, L.network.params, L.rms, L.mom, L.grad, L.lr_dev,
+              L.gnorm_dev, L.loss_dev]
+        for name in ("raw", "walk_scratch", "mt_state"):
+            t = getattr(self, name, None)
+            if t is not None:
+                ts.append(t)
+        return ts
+
+    def _replay_matches_eager(self):
+        """One cycle from the current state with the all-reduce issued eagerly, the state put back, the same cycle replayed
+        from the captured graph (all-reduce inside), the state put back again: True when the two exchanged gradients are
+        bit-identical.  Nothing of either run survives: training starts from the state this was called in."""
+        L = self.L
+        state = self._cycle_state()
+        saved = [t.clone() for t in state]
+
+        def restore():
+            for t, s in zip(state, saved):
+                t.copy_(s)
+            L.ctx.pack_weights(L.network.params)          # the optimizer step re-packed the updated weights
+
+        self._rollout_and_backward(0)
+        self._exchange(None)
+        eager = L.grad.clone()
+        self._update()                                    # (consumes what the backward left pending in the ctx)
+        restore()
+        self.graph_a[0].launch()                          # backward -> captured all-reduce -> update; grad stays as exchanged
+        replayed = L.grad.clone()
+        restore()
+        self.stream.synchronize()
+        return bool(torch.equal(eager, replayed))
+
+    def check_replicas(self, what="weights"):
+        """Data parallel: all ranks must hold bit-identical weights and optimizer slots (identical start, identical
+        all-reduced gradient, identical update).  Raises parallel.ReplicaMismatch on every rank when they do not."""
+        L = self.L
+        self.synchronize()
+        names = ("params", "rms", "mom") if what == "weights" else ("grad",)
+        tensors = [L.network.params, L.rms, L.mom] if what == "weights" else [L.grad]
+        with torch.cuda.stream(self.stream):
+            ok, same = parallel.replicas_identical(tensors)
+        if not ok:
+            bad = [n for n, s in zip(names, same) if not s]
+            raise parallel.ReplicaMismatch("data-parallel replicas diverged: %s differ between ranks (exchange mode %s, rank %d of %d)"
+                                           % (", ".join(bad), self.exchange_mode, parallel.rank(), parallel.world_size()))
+        return True
+
     # cycles per launch of graph_multi / graph_multi_long (even: the ring parity is back at 0 afterwards).  Measured at the
     # headline configuration, cycles per launch 4 / 8 / 16 / 32: 643.5 / 645.6 / 648.6 / 648.1 k env-steps/s.
     MULTI = max(2, int(os.environ.get("PAAC_CYCLES_PER_LAUNCH", "4")) // 2 * 2)
@@ -252,11 +325,12 @@ class DeviceRollout(object):
         """`count` cycles.  Graph replay batches them MULTI_LONG or MULTI per hipGraph launch where it can: the gap between
         two graph launches on the GPU (about 8 us) is paid once per batch instead of every cycle."""
         count = int(count)
+        if self.use_graph and self.graph_a[0] is None and count > 0:
+            with torch.cuda.stream(self.stream):
+                self.capture()            # first: a captured exchange that is refused changes which graphs exist
         while count > 0:
             if self.use_graph and (not self.phased or self.graph_exchange) and self.parity == 0 and count >= self.MULTI:
                 with torch.cuda.stream(self.stream):
-                    if self.graph_a[0] is None:
-                        self.capture()
                     if self.graph_multi_long is not None and count >= self.MULTI_LONG:
                         self.graph_multi_long.launch()
                         count -= self.MULTI_LONG
@@ -449,7 +523,17 @@ class PAACLearner(ActorLearner):
         episodes_seen = 0
         from .actor_learner import CHECKPOINT_INTERVAL
         since_stop_check = 0
+        # data parallel: the replicas are compared (checksums of weights and optimizer slots, MIN / MAX over ranks) right
+        # after the first update -- with the exchanged gradient -- and then every PAAC_REPLICA_CHECK_CYCLES cycles; a
+        # mismatch ends the run on every rank (parallel.ReplicaMismatch -> non-zero exit)
+        check_every = max(1, int(os.environ.get("PAAC_REPLICA_CHECK_CYCLES", "1024")))
+        next_check = 1 if parallel.collectives_active() else None
         while self.global_step < self.max_global_steps:
+            if next_check is not None and counter >= next_check:
+                if next_check == 1:
+                    self.rollout.check_replicas("grad")
+                self.rollout.check_replicas("weights")
+                next_check = counter + check_every
             if world == 1:
                 if self.stop_requested:
                     break
@@ -466,6 +550,8 @@ class PAACLearner(ActorLearner):
                 until_log = int(log_every) - counter % int(log_every)
                 until_save = -(-(self.last_saving_step + CHECKPOINT_INTERVAL - self.global_step) // steps_per_cycle)
                 chunk = max(1, min(until_end, until_log, until_save))
+            if next_check is not None:
+                chunk = max(1, min(chunk, next_check - counter))
             self.rollout.run_cycles(chunk)
             self.global_step += chunk * steps_per_cycle
             counter += chunk
@@ -486,6 +572,8 @@ class PAACLearner(ActorLearner):
                                           (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
             self.save_vars()          # _sync_device() flushes the rollout first when a checkpoint is due
         self.rollout.synchronize()
+        if next_check is not None:
+            self.rollout.check_replicas("weights")
 
     # -- host-environment loop (the reference's structure, kernels instead of session.run) ------------
     def _train_host(self):
@@ -551,6 +639,7 @@ class PAACLearner(ActorLearner):
         # data parallel: global_step counts the environment steps of ALL ranks (paac.py:127 counts every environment of
         # the one learner), like the device loop -- lr anneals and max_global_steps ends on the global count
         world = self._world()
+        check_every = max(1, int(os.environ.get("PAAC_REPLICA_CHECK_CYCLES", "1024")))
 
         stock_rescale = type(self).rescale_reward is ActorLearner.rescale_reward
 
@@ -615,6 +704,11 @@ class PAACLearner(ActorLearner):
             if getattr(self.args, "cycle_callback", None):      # bench hook: one call per finished cycle, nothing copied
                 self.args.cycle_callback(self.global_step)
             counter += 1
+            if parallel.collectives_active() and (counter == 1 or counter % check_every == 0):
+                ok, same = parallel.replicas_identical([params, self.rms, self.mom])
+                if not ok:
+                    raise parallel.ReplicaMismatch("data-parallel replicas diverged after %d updates: %s differ between ranks"
+                                                   % (counter, ", ".join(n for n, s in zip(("params", "rms", "mom"), same) if not s)))
             if counter % (2048 / self.emulator_counts) == 0:
                 curr_time = time.time()
                 last_ten = 0.0 if len(total_rewards) < 1 else np.mean(total_rewards[-10:])

@@ -80,6 +80,49 @@ def any_rank(flag, device):
     return bool(int(t.item()))
 
 
+def all_ranks(flag, device):
+    """Logical AND of a host flag over all ranks (a fallback decision every rank must take together)."""
+    if world_size() <= 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+                     device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+_weights = {}
+
+
+def checksum64(t):
+    """Position-weighted 64-bit checksum of a tensor's bits (device scalar, wraps modulo 2^64): equal tensors give equal sums,
+    a flipped bit or two swapped elements change it."""
+    bits = t.detach().contiguous().view(-1)
+    bits = bits.view(torch.int32) if bits.element_size() == 4 else bits.to(torch.int32)
+    key = (bits.numel(), bits.device)
+    if key not in _weights:
+        _weights[key] = (torch.arange(bits.numel(), dtype=torch.int64, device=bits.device) % 1000003) * 2 + 1
+    return (bits.to(torch.int64) * _weights[key]).sum()
+
+
+def replicas_identical(tensors):
+    """Do all ranks hold bit-identical copies of `tensors`?  MIN and MAX all-reduce of their checksums; every rank gets the
+    same answer.  -> (identical, [per-tensor bool]).  One process: trivially true."""
+    sums = torch.stack([checksum64(t) for t in tensors])
+    if world_size() <= 1:
+        return True, [True] * len(tensors)
+    if dist.get_backend() != "nccl":
+        sums = sums.cpu()
+    lo, hi = sums.clone(), sums.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = (lo == hi).cpu().tolist()
+    return all(same), same
+
+
+class ReplicaMismatch(RuntimeError):
+    """The data-parallel replicas no longer hold identical weights: the run cannot continue."""
+
+
 def backend():
     """Backend of the default process group ("nccl" = RCCL, "gloo"), None without a group."""
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else None

@@ -150,7 +150,13 @@ def main(args):
     learner = PAACLearner(network_creator, env_creator, args)
     setup_kill_signal_handler(learner)
     logging.info('Starting training (%d data-parallel rank%s)', world, '' if world == 1 else 's')
-    learner.train()
+    try:
+        learner.train()
+    except parallel.ReplicaMismatch as exc:
+        # every rank raises at the same cycle (the comparison is itself a collective): no checkpoint of diverged weights,
+        # no collective cleanup, a non-zero exit code for the launcher
+        logging.error('%s -- stopping', exc)
+        sys.exit(3)
     logging.info('Finished training')
     parallel.shutdown()
 

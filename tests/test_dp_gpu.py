@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_dir, n_per_rank, cycles, mode="single"):
+def _run(rank, world, port, out_dir, n_per_rank, cycles, mode="single", corrupt=False):
     os.environ["PAAC_ALLREDUCE"] = mode
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -51,8 +51,24 @@ def _run(rank, world, port, out_dir, n_per_rank, cycles, mode="single"):
     ro.synchronize()
     acts.append(ro.actions.cpu().numpy().copy())
     p = L.network.get_parameters()
+    verdict = {}
+    if world > 1:
+        from paac_amd import parallel
+        assert ro.check_replicas("grad") and ro.check_replicas("weights")       # identical after `cycles` exchanged updates
+        if corrupt:
+            # one rank's weights drift by one element: EVERY rank must see the mismatch (the comparison is a collective),
+            # also after more cycles
+            if rank == 1:
+                L.network.params[12345] += 1e-3
+            for when in ("at once", "after two more cycles"):
+                try:
+                    ro.check_replicas("weights")
+                    verdict[when] = "identical"
+                except parallel.ReplicaMismatch as exc:
+                    verdict[when] = str(exc)
+                ro.run_cycles(2)
     np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), actions=np.stack(acts),
-             gstep=int(ro.global_step_dev.item()), lr=float(L.lr_dev.item()), **p)
+             gstep=int(ro.global_step_dev.item()), lr=float(L.lr_dev.item()), verdict=np.array(sorted(verdict.items())), **p)
     ro.close()
     if world > 1:
         dist.barrier()
@@ -74,10 +90,23 @@ def test_two_ranks_track_single_process(tmp_path, mode):
     # first cycle: identical weights -> identical actions per environment (philox is keyed by the global env id)
     assert np.array_equal(np.concatenate([r0["actions"][0], r1["actions"][0]], axis=1), one["actions"][0])
     for k in one.files:
-        if k in ("actions", "gstep", "lr"):
+        if k in ("actions", "gstep", "lr", "verdict"):
             continue
         assert np.array_equal(r0[k], r1[k]), "replicated weights diverged: %s" % k
         assert np.abs(r0[k] - one[k]).max() < 2e-5, k
+
+
+def test_diverged_replicas_are_detected_on_every_rank(tmp_path):
+    """DeviceRollout.check_replicas (what train.py and bench.py call after the first update and every
+    PAAC_REPLICA_CHECK_CYCLES cycles): MIN / MAX all-reduce of 64-bit checksums of weights and optimizer slots.  Identical
+    replicas pass; one element changed on ONE rank raises parallel.ReplicaMismatch on BOTH."""
+    import torch.multiprocessing as mp
+    mp.spawn(_run, args=(2, _free_port(), str(tmp_path), 4, 3, "single", True), nprocs=2, join=True)
+    for r in (0, 1):
+        verdict = dict(np.load(tmp_path / ("w2_r%d.npz" % r))["verdict"].tolist())
+        assert set(verdict) == {"at once", "after two more cycles"}
+        for when, text in verdict.items():
+            assert "replicas diverged" in text and "params" in text, (r, when, text)
 
 
 def test_bench_two_rank_rehearsal():
@@ -98,6 +127,10 @@ def test_bench_two_rank_rehearsal():
     assert out["n_gpus"] == 2 and out["steps"] == 12 and out["scaling"] == "weak" and out["finite_params"]
     assert out["config"]["global_envs"] == 64 and out["cpu_baseline"] is None
     assert out["roofline"]["bound"] in ("mfma", "hbm") and out["value"] > 0
+    # the replicas were compared (after the warm-up and after the timed windows) and the line says how the exchange ran:
+    # gloo cannot be captured, so the requested graph mode reports the eager form it really used
+    assert out["replicas_identical"] is True
+    assert out["exchange"]["mode"] == "single" and out["exchange"]["requested"] == "graph"
 
 
 _RCCL_SMOKE = r"""
@@ -116,9 +149,9 @@ args.emulator_counts, args.max_local_steps, args.emulator_workers = 8, 5, 0
 args.max_global_steps = 1 << 40
 args.synthetic_terminal_p = 0.1
 out = {}
-for mode in ("plain", "split", "single", "graph"):
+for mode in ("plain", "split", "single", "graph", "graph_refused"):
     os.environ["PAAC_FORCE_COLLECTIVES"] = "0" if mode == "plain" else "1"
-    os.environ["PAAC_ALLREDUCE"] = mode if mode != "plain" else "single"
+    os.environ["PAAC_ALLREDUCE"] = "graph" if mode == "graph_refused" else mode if mode != "plain" else "single"
     args.debugging_folder = tempfile.mkdtemp(prefix="paac_rccl_")
     nc, ec = train.get_network_and_environment_creator(args)
     L = PAACLearner(nc, ec, args)
@@ -126,15 +159,28 @@ for mode in ("plain", "split", "single", "graph"):
     np.random.seed(4)
     ro = DeviceRollout(L, ec.device_env_spec, sampler="numpy", use_graph=True)
     assert ro.phased == (mode != "plain")
+    checked = []
+    if mode == "graph":            # the replayed cycle is compared with the eager exchange before it is trusted ...
+        inner = ro._replay_matches_eager
+        ro._replay_matches_eager = lambda: checked.append(inner()) or checked[-1]
+    if mode == "graph_refused":    # ... and a replay that does not reproduce it is refused: the eager form takes over
+        ro._replay_matches_eager = lambda: False
     ro.run_cycles(7)
     ro.synchronize()
     out[mode] = (L.network.params.cpu().numpy().copy(), ro.actions.cpu().numpy().copy(), int(ro.global_step_dev.item()))
     assert ro.graph_exchange == (mode == "graph")
-    assert (ro.graph_ua[0] is not None) == (mode in ("split", "single"))
+    assert ro.exchange_mode == {"plain": "none", "graph_refused": "single"}.get(mode, mode)
+    if mode == "graph":
+        assert checked == [True] and ro.exchange_fallback is None
+    if mode == "graph_refused":
+        assert "differs from the eager" in ro.exchange_fallback
+    if mode != "plain":
+        assert ro.check_replicas("weights") and ro.check_replicas("grad")
+    assert (ro.graph_ua[0] is not None) == (mode in ("split", "single", "graph_refused"))
     assert (ro.graph_conv[0] is not None) == (mode == "split")
     assert (ro.graph_multi is not None) == (mode in ("plain", "graph"))      # MULTI cycles per launch survive the exchange
     ro.close()
-for mode in ("split", "single", "graph"):
+for mode in ("split", "single", "graph", "graph_refused"):
     assert np.array_equal(out[mode][0], out["plain"][0]), mode + ": weights differ from the unphased run"
     assert np.array_equal(out[mode][1], out["plain"][1]) and out[mode][2] == out["plain"][2]
 parallel.shutdown()
@@ -152,6 +198,8 @@ def test_phased_exchange_runs_under_rccl_world_of_one():
                MASTER_PORT=str(_free_port()))
     res = subprocess.run([sys.executable, "-c", _RCCL_SMOKE % dict(root=ROOT)], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=600)
+    if res.returncode != 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # the whole log, for the post-mortem
+        open(os.path.join(ROOT, "gpurun_out", "rccl_smoke_failure.txt"), "w").write(res.stdout + "\n--- stderr ---\n" + res.stderr)
     assert res.returncode == 0 and "RCCL_SMOKE_OK" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
 
 

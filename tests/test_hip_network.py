@@ -23,6 +23,28 @@ def make_case(arch, A, B, seed=0, weight_scale=1.0):
     return params, states, idx, y, adv
 
 
+# Weights scaled so that the network behaves like a TRAINED one: |logits| and |v| of order 5-20 (initialisation-scale
+# weights give +-0.03, where an absolute 1e-4 is a 0.3 % relative bar), some policies saturated (p < 6e-8: the
+# `p - epsneg < 0` case of paac.py:42).  Measured on MI355X (tools/probe_magnitudes.py): logit / value errors 4e-6 .. 1.6e-5,
+# activation errors <= 1.3e-6 of the layer's maximum, gradients 1e-6 relative.
+TRAINED = 3.5        # |logits| ~ 5-10, |v| ~ 6-9
+SATURATED = 4.0      # |logits| ~ 11-19, p_min down to 4e-14
+
+
+def check_activations(ctx, ref_cache, arch, B, weight_scale):
+    """conv / fc activations against the float64 oracle: the absolute 2e-5 (conv) / 5e-5 (fc) bars at initialisation scale, a
+    RELATIVE bar -- 1e-5 of the layer's largest activation -- whatever the weights."""
+    nconv = 3 if arch == "NATURE" else 2
+    for i in list(range(1, nconv + 1)) + [4]:
+        got = ctx.debug_activation(i, B).cpu().numpy()
+        want = ref_cache["a%d" % i if i < 4 else "h"].reshape(-1)
+        assert got.shape == want.shape
+        err = np.abs(got - want).max()
+        assert err <= 1e-5 * np.abs(want).max(), "layer %d: max abs err %g of max %g" % (i, err, np.abs(want).max())
+        if weight_scale == 1.0:
+            assert err < (2e-5 if i < 4 else 5e-5), "layer %d: max abs err %g" % (i, err)
+
+
 def upload_params(ctx, params):
     from paac_amd import _lib
     lay = ctx.layout
@@ -47,8 +69,27 @@ def unflatten(ctx, flat):
                                       # BASELINE configs[4] per-GPU shard (Seaquest A=18, 128 envs, t_max 20)
                                       ("NATURE", 18, 128), ("NATURE", 18, 2688)])
 def test_forward_parity(arch, A, B):
+    _forward_parity(arch, A, B, 1.0)
+
+
+@pytest.mark.parametrize("arch,A,B,scale", [
+    ("NATURE", 4, 32, TRAINED), ("NATURE", 4, 192, TRAINED), ("NATURE", 4, 192, SATURATED),     # configs[1]: acting / training rows
+    ("NATURE", 4, 256, TRAINED), ("NATURE", 4, 1536, SATURATED),                                # configs[2]
+    ("NATURE", 6, 192, TRAINED),                                                                # configs[3] shard
+    ("NATURE", 18, 128, SATURATED), ("NATURE", 18, 2688, TRAINED),                              # configs[4] shard
+    ("NIPS", 6, 40, SATURATED), ("NIPS", 6, 1280, TRAINED)])                                    # configs[0]'s network
+def test_forward_parity_at_trained_magnitudes(arch, A, B, scale):
+    """north_star's "logits within 1e-4" in the regime it is about: logits and values of order 5-20 (1e-4 absolute = 1e-5
+    relative), saturated policies included (policy_v_network.py:24-57, networks.py:84-89)."""
+    ref = _forward_parity(arch, A, B, scale)
+    assert np.abs(ref["logits"]).max() > 4.0 and np.abs(ref["v"]).max() > 2.0
+    if scale == SATURATED:
+        assert ref["pi"].min() < 5.9604645e-08          # rows the sampler sees as p - epsneg < 0
+
+
+def _forward_parity(arch, A, B, weight_scale):
     from paac_amd import hip_ops
-    params, states, idx, y, adv = make_case(arch, A, B, seed=1)
+    params, states, idx, y, adv = make_case(arch, A, B, seed=1, weight_scale=weight_scale)
     ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=max(B, 8))
     p = upload_params(ctx, params)
     s = torch.from_numpy(states).cuda()
@@ -58,29 +99,24 @@ def test_forward_parity(arch, A, B):
     ctx.forward(p, s, logits, probs, values)
     torch.cuda.synchronize()
     ref = onet.forward(params, states, arch, dtype=np.float64, keep=True)
-    nconv = 3 if arch == "NATURE" else 2
-    for i in range(nconv):
-        got = ctx.debug_activation(i + 1, B).cpu().numpy()
-        want = ref["cache"]["a%d" % (i + 1)].reshape(-1)
-        assert got.shape == want.shape
-        err = np.abs(got - want).max()
-        assert err < 2e-5, "conv%d activations: max abs err %g" % (i + 1, err)
-    h = ctx.debug_activation(4, B).cpu().numpy()
-    assert np.abs(h - ref["cache"]["h"].reshape(-1)).max() < 5e-5
+    check_activations(ctx, ref["cache"], arch, B, weight_scale)
     # north_star tolerance: logits / values within 1e-4 of the reference-equivalent CPU path
     assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
     assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
     assert np.abs(probs.cpu().numpy() - ref["pi"]).max() < 1e-5
     ctx.close()
+    return ref
 
 
-@pytest.mark.parametrize("A,B", [(18, 128), (4, 256), (6, 65), (18, 200), (4, 64), (32, 100)])
-def test_managed_acting_forward_parity(A, B):
+@pytest.mark.parametrize("A,B,scale", [(18, 128, 1.0), (4, 256, 1.0), (6, 65, 1.0), (18, 200, 1.0), (4, 64, 1.0), (32, 100, 1.0),
+                                       # trained-network magnitudes (see TRAINED / SATURATED): configs[1], [2], [4] acting rows
+                                       (4, 32, SATURATED), (4, 256, TRAINED), (18, 128, SATURATED), (6, 32, TRAINED)])
+def test_managed_acting_forward_parity(A, B, scale):
     """The acting forward of the learner (managed weights: conv tower -> fc with the head contractions in its epilogue ->
     heads finish by one workgroup up to 64 rows, by a few -- heads_finish_rows_kernel -- up to 256) against the oracle: the
     128- and 256-environment shards' policy step."""
     from paac_amd import hip_ops
-    params, states, idx, y, adv = make_case("NATURE", A, B, seed=5)
+    params, states, idx, y, adv = make_case("NATURE", A, B, seed=5, weight_scale=scale)
     ctx = hip_ops.Context(ARCH_ID["NATURE"], A, max_batch=B)
     p = upload_params(ctx, params)
     ctx.set_managed_weights(True)
@@ -92,6 +128,8 @@ def test_managed_acting_forward_parity(A, B):
     ctx.forward(p, s, logits, probs, values)
     torch.cuda.synchronize()
     ref = onet.forward(params, states, "NATURE", dtype=np.float64)
+    if scale != 1.0:
+        assert np.abs(ref["logits"]).max() > 4.0 and np.abs(ref["v"]).max() > 2.0
     assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
     assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
     assert np.abs(probs.cpu().numpy() - ref["pi"]).max() < 1e-5
@@ -106,8 +144,22 @@ def test_managed_acting_forward_parity(A, B):
                                       ("NATURE", 6, 160),      # configs[3] shard: 32 envs x t_max 5, Qbert action set
                                       ("NATURE", 18, 2560)])   # configs[4] shard: 128 envs x t_max 20, Seaquest action set
 def test_backward_parity(arch, A, B):
+    _backward_parity(arch, A, B, 1.0)
+
+
+@pytest.mark.parametrize("arch,A,B,scale", [("NATURE", 4, 160, TRAINED), ("NATURE", 4, 160, SATURATED),     # configs[1]
+                                            ("NATURE", 4, 1280, TRAINED),                                   # configs[2]
+                                            ("NATURE", 18, 2560, SATURATED),                                # configs[4] shard
+                                            ("NIPS", 6, 40, TRAINED)])
+def test_backward_parity_at_trained_magnitudes(arch, A, B, scale):
+    """Loss terms and every gradient at trained-network magnitudes (saturated policies: log(pi + 1e-30) far from 0,
+    policy_v_network.py:29-35), same bars: 1e-4 relative."""
+    _backward_parity(arch, A, B, scale)
+
+
+def _backward_parity(arch, A, B, weight_scale):
     from paac_amd import hip_ops
-    params, states, idx, y, adv = make_case(arch, A, B, seed=2)
+    params, states, idx, y, adv = make_case(arch, A, B, seed=2, weight_scale=weight_scale)
     ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
     p = upload_params(ctx, params)
     s = torch.from_numpy(states).cuda()
@@ -129,7 +181,7 @@ def test_backward_parity(arch, A, B):
                                    relu_masks=masks)
     lo = loss.cpu().numpy()
     assert abs(lo[0] - L["loss"]) < 1e-4 * max(1.0, abs(L["loss"]))
-    assert abs(lo[1] - L["actor"]) < 1e-4 and abs(lo[2] - L["critic"]) < 1e-4
+    assert abs(lo[1] - L["actor"]) < 1e-4 * max(1.0, abs(L["actor"])) and abs(lo[2] - L["critic"]) < 1e-4 * max(1.0, abs(L["critic"]))
     assert abs(lo[3] - L["entropy"].mean()) < 1e-4
     got = unflatten(ctx, grad)
     gn_ref = onet.global_norm(g_ref)
@@ -333,12 +385,13 @@ def test_conv1_exact_bf16_path(B, fwd_cfg, wgrad_cfg):
 @pytest.mark.parametrize("arch,A,B,cfg_fwd,cfg_dgrad,cfg_wgrad", [("NATURE", 4, 160, 204, 205, 200), ("NATURE", 6, 32, 201, 201, 201),
                                                                   ("NIPS", 6, 72, 207, 210, 203), ("NATURE", 4, 45, 211, 209, 203),
                                                                   ("NATURE", 4, 192, 212, 211, 201), ("NIPS", 18, 33, 210, 209, 200)])
-def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
+@pytest.mark.parametrize("scale", [1.0, SATURATED])
+def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad, scale):
     """Every contraction on the six-product split-bf16 path (dmm.h: XB = 2; the ids are entries of
     PAAC_*_SPLIT_CFGS, i.e. really instantiated there): the same parity bars as the fp32 MFMA path -- logits / values
     within 1e-4, gradients within 1e-4 of the float64 oracle."""
     from paac_amd import hip_ops, _lib
-    params, states, idx, y, adv = make_case(arch, A, B, seed=9)
+    params, states, idx, y, adv = make_case(arch, A, B, seed=9, weight_scale=scale)
     ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
     cls = 1 if B > 64 else 0
     for op in (1, 2, 3):
@@ -356,9 +409,7 @@ def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
     assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
     assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
     nconv = 3 if arch == "NATURE" else 2
-    for i in range(nconv):
-        got = ctx.debug_activation(i + 1, B).cpu().numpy()
-        assert np.abs(got - ref["cache"]["a%d" % (i + 1)].reshape(-1)).max() < 2e-5
+    check_activations(ctx, ref["cache"], arch, B, scale)
     grad = torch.zeros(ctx.layout["total"], device="cuda")
     ctx.loss_backward(p, s, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(adv).cuda(), 0.02,
                       grad)
@@ -376,13 +427,13 @@ def test_split_bf16_path(arch, A, B, cfg_fwd, cfg_dgrad, cfg_wgrad):
 
 
 @pytest.mark.parametrize("regions", [8, 4, 2, 1])
-@pytest.mark.parametrize("B,A", [(5, 4), (33, 6)])
-def test_conv_tower_variants(regions, B, A):
+@pytest.mark.parametrize("B,A,scale", [(5, 4, 1.0), (33, 6, 1.0), (32, 4, SATURATED)])
+def test_conv_tower_variants(regions, B, A, scale):
     """csrc/tower.h: the fused conv1->conv2->conv3 launch in each of its region layouts (4 overlapping 4x4 regions, 2
     halves, one workgroup per sample) against the float64 oracle -- conv1 / conv2 / conv3 activations, logits, values --
     and against the unfused per-layer kernels (PAAC_TOWER=0 is the same arithmetic in a different summation order)."""
     from paac_amd import _lib, hip_ops
-    params, states, idx, y, adv = make_case("NATURE", A, B, seed=3)
+    params, states, idx, y, adv = make_case("NATURE", A, B, seed=3, weight_scale=scale)
     ctx = hip_ops.Context(ARCH_ID["NATURE"], A, max_batch=B)
     for cls in (0, 1, 2):
         _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, 11, cls, regions, 0, -1), "set_tuning")
@@ -393,12 +444,7 @@ def test_conv_tower_variants(regions, B, A):
     ctx.forward(p, s, logits=logits, values=values)
     torch.cuda.synchronize()
     ref = onet.forward(params, states, "NATURE", dtype=np.float64, keep=True)
-    for i in (1, 2, 3):
-        got = ctx.debug_activation(i, B).cpu().numpy()
-        want = ref["cache"]["a%d" % i].reshape(-1)
-        assert got.shape == want.shape
-        err = np.abs(got - want).max()
-        assert err < 2e-5, "regions=%d conv%d: max abs err %g" % (regions, i, err)
+    check_activations(ctx, ref["cache"], "NATURE", B, scale)
     assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
     assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
     # managed mode: the acting forward keeps only conv3's output; weights come from an explicit pack
@@ -613,4 +659,70 @@ def test_profiling_hooks_name_the_launches_and_their_instruction_mix():
     assert got[("dgrad_tower", B)] == (6,)
     assert got[("heads_fwd", 32)] == () and ("conv3_wgrad", B) not in got and ("conv2_wgrad", B) not in got
     assert ctx.prof_read() == []                              # the table was cleared
+    ctx.close()
+
+
+@pytest.mark.parametrize("A,T,N,scale", [(4, 5, 32, 1.0), (4, 5, 32, TRAINED), (18, 3, 128, 1.0), (6, 2, 7, 1.0), (4, 2, 256, TRAINED)])
+def test_update_from_kept_acting_rows(A, T, N, scale):
+    """paac_keep_next_forward + paac_bootstrap_forward_trunk: the T acting forwards keep their rows in the training activation
+    set, the bootstrap observations run as one acting-shaped forward, and the backward starts from there -- no training
+    forward (weights are frozen inside a cycle: paac.py:105 and :163-165 evaluate the same network on the same
+    observations).  Against the recomputed route (paac_train_forward_trunk): same returns, gradient equal to fp32 summation
+    order; against the float64 oracle: activations of the kept rows, gradient within the usual bars."""
+    from paac_amd import hip_ops, _lib
+    B = T * N
+    params, states, idx, _, _ = make_case("NATURE", A, B + N, seed=41, weight_scale=scale)
+    ctx = hip_ops.Context(ARCH_ID["NATURE"], A, max_batch=B + N)
+    p = upload_params(ctx, params)
+    ctx.set_managed_weights(True)
+    ctx.pack_weights(p)
+    rs = np.random.RandomState(6)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    s, acts = dev(states), dev(idx[:B])
+    rewards = dev(rs.choice([-1.0, 0.0, 1.0], size=(T, N)).astype(np.float32))
+    masks = dev((rs.rand(T, N) > 0.2).astype(np.float32))
+    n = ctx.layout["total"]
+    out = []
+    for kept in (False, True):
+        values = torch.zeros((T, N), device="cuda")
+        probs = torch.zeros((N, A), device="cuda")
+        for t in range(T):                          # the acting forwards of the rollout (they produce values[t] either way)
+            if kept:
+                ctx.keep_next_forward(t * N)
+            ctx.forward(p, s[t * N:(t + 1) * N], probs=probs, values=values[t])
+        if kept:
+            ctx.bootstrap_forward_trunk(p, s[B:], B)
+        else:
+            ctx.train_forward_trunk(p, s)
+        y, adv = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+        grad, loss = torch.zeros(n, device="cuda"), torch.zeros(4, device="cuda")
+        ctx.loss_backward_returns(p, s[:B], acts, None, rewards, masks, values, 0.99, y, adv, 0.02, grad, loss, phase=3,
+                                  forward_done=True)
+        ms, mom, gn = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+        q = p.clone()
+        ctx.clip_rmsprop(q, grad, ms, mom, torch.tensor([0.01], device="cuda"), 0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL, gnorm_out=gn)
+        ctx.pack_weights(p)                          # the optimizer step re-packed q's weights: back to p's for the next route
+        torch.cuda.synchronize()
+        acts_kept = [ctx.debug_activation(i, B + N).cpu().numpy() for i in (1, 2, 3, 4)] if kept else None
+        out.append(dict(grad=grad.cpu().numpy(), y=y.cpu().numpy(), adv=adv.cpu().numpy(), loss=loss.cpu().numpy(),
+                        gn=float(gn.item()), values=values.cpu().numpy(), acts=acts_kept))
+    a, b = out
+    assert np.array_equal(a["values"], b["values"])                         # the acting forward itself does not change
+    assert np.abs(a["y"] - b["y"]).max() <= 2e-6 * max(1.0, np.abs(a["y"]).max())      # bootstrap values: another summation order
+    scale_g = np.abs(a["grad"]).max()
+    assert np.abs(a["grad"] - b["grad"]).max() <= 2e-5 * scale_g
+    assert abs(a["gn"] - b["gn"]) <= 1e-5 * a["gn"]
+    assert np.abs(a["loss"] - b["loss"]).max() <= 1e-5 * max(1.0, np.abs(a["loss"]).max())
+    # the kept rows against the oracle
+    ref = onet.forward(params, states, "NATURE", dtype=np.float64, keep=True)["cache"]
+    for i, got in zip((1, 2, 3, 4), b["acts"]):
+        want = ref["a%d" % i if i < 4 else "h"].reshape(-1)
+        assert got.shape == want.shape
+        if i == 4:          # fc activations: the update's B rows (the bootstrap rows' stay in the kept slab, read for v only)
+            got, want = got[:B * 512], want[:B * 512]
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), "kept layer %d" % i
+    # a forward that cannot keep its rows says so
+    ctx.keep_next_forward(B)                        # rows [B, B + N + 1) do not fit the training set
+    with pytest.raises(Exception):
+        ctx.forward(p, s[:N + 1], values=torch.zeros(N + 1, device="cuda"))
     ctx.close()

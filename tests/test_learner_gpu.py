@@ -151,6 +151,8 @@ def test_device_loop_matches_host_loop(raw_frames, use_graph):
     ("breakout", 256, 5, 1, "NATURE", True),
     ("breakout", 32, 5, 2, "NATURE", True),
     ("qbert", 9, 3, 2, "NATURE", True),
+    # twenty updates at the headline shape: the weights move (lr 0.0224, clip 3.0) and the actions stay bit-equal
+    ("breakout", 32, 5, 20, "NATURE", False),
 ])
 def test_device_loop_matches_oracle(game, N, T, cycles, arch, raw):
     """The device-resident cycle (hipGraph replay, numpy-parity sampler) against the CPU restatement of paac.py:99-165

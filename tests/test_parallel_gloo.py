@@ -76,6 +76,39 @@ def test_sharded_gradient_equals_full_batch(tmp_path):
     assert np.abs(r0["flat"] - full["flat"]).max() / scale < 1e-12   # == gradient of the concatenated batch
 
 
+def _checksum_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from paac_amd import parallel
+    rs = np.random.RandomState(3)
+    w = torch.from_numpy(rs.randn(100003).astype(np.float32))
+    slots = torch.ones(777)
+    res = [parallel.replicas_identical([w, slots])]
+    if rank == 1:
+        w[99999] = w[99999] + 1e-7 * (1 + abs(w[99999]))          # one element, the last bit or two
+    res.append(parallel.replicas_identical([w, slots]))
+    w2 = w.clone()
+    if rank == 1:
+        w2[5], w2[6] = w[6].clone(), w[5].clone()                 # two elements swapped: the checksum is position-weighted
+    res.append(parallel.replicas_identical([slots, w2]))
+    flags = [parallel.all_ranks(True, "cpu"), parallel.all_ranks(rank == 0, "cpu"), parallel.any_rank(rank == 1, "cpu")]
+    np.save(os.path.join(out_dir, "cs%d.npy" % rank), np.array([str(res), str(flags)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_checksums_agree_on_every_rank(tmp_path):
+    """parallel.replicas_identical / all_ranks: what keeps a diverged or half-fallen-back data-parallel run from going on."""
+    world = 2
+    mp.spawn(_checksum_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "cs0.npy"), np.load(tmp_path / "cs1.npy")
+    assert list(a) == list(b)                                      # every rank reaches the same verdicts
+    assert a[0] == str([(True, [True, True]), (False, [False, True]), (False, [True, False])])
+    assert a[1] == str([True, False, True])
+
+
 def test_shard_range_validation():
     from paac_amd import parallel
     assert parallel.shard_range(32, 3, 8) == (12, 16)
