@@ -134,13 +134,19 @@ int paac_bootstrap_forward_trunk(paac_ctx* ctx, const float* params, const uint8
  * raw_scratch (nullable, [N,2,210,160] u8): path B like paac_synth_step's -- the step launch writes the step's raw screen
  * pairs there instead of shifting the stacks, and one more launch (paac_preprocess_stack's kernel: max of the two screens,
  * PIL-nearest resize, history push, reset on terminal) builds stack_out / stack_out2 from them: four launches.
- * Requires N <= PAAC_ACT_STEP_MAX_ENVS and N*(A-1) <= 1024. */
+ * Up to PAAC_ACT_STEP_MAX_ENVS environments and N*(A-1) <= 1024 draws: the three launches above.  Beyond, up to
+ * PAAC_ACT_STEP_MAX_ENVS_LARGE environments and PAAC_FUSED_SAMPLE_MAX_DRAWS draws (the 128 x 18 and 256 x 4 shards):
+ * paac_forward + paac_sample_mt_synth_step in one call (four launches; lend walk_scratch as there), with the sampler's
+ * MT19937 doubles made one launch ahead by a spare workgroup of the fc launch (they depend on nothing but the stream
+ * position), so that the sampler workgroups load them instead of each rebuilding the state blocks. */
 #define PAAC_ACT_STEP_MAX_ENVS 64
+#define PAAC_ACT_STEP_MAX_ENVS_LARGE 256
 int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, uint32_t* mt_state,
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
                      uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
                      uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
-                     void* finished, uint8_t* raw_scratch, paac_stream_t stream);
+                     void* finished, uint8_t* raw_scratch, void* walk_scratch, int64_t walk_scratch_bytes,
+                     paac_stream_t stream);
 
 /* Conv-weight packing.  The Nature conv layers run as one fused launch that reads the conv weights pre-split into bf16
  * planes (an internal copy owned by the ctx).  By default every paac_forward* / paac_train_forward / paac_loss_backward

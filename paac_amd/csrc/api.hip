@@ -191,12 +191,17 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   PAAC_CHECK_HIP(hipMemset(c->zeros, 0, (size_t)(c->spec.fc > 1024 ? c->spec.fc : 1024) * sizeof(float)));
   c->keep_row = -1;
   c->heads_pending_h = 0;
+  PAAC_CHECK_HIP(hipMalloc(&c->mt_ahead, mt_ahead_bytes()));
+  PAAC_CHECK_HIP(hipMemset(c->mt_ahead, 0, mt_ahead_bytes()));
+  c->ahead_state = nullptr;
+  c->ahead_D = 0;
   {
     const char* v = getenv("PAAC_TOWER");
     c->tower_on = (cfg->arch == PAAC_ARCH_NATURE) && !(v && *v && atoi(v) == 0);
+    c->tower2_on = (cfg->arch == PAAC_ARCH_NIPS) && tower2_available() && !(v && *v && atoi(v) == 0);
     c->managed_weights = 0;
     c->tower_pack = nullptr;
-    if (c->tower_on) PAAC_CHECK_HIP(hipMalloc(&c->tower_pack, tower_pack_bytes()));
+    if (c->tower_on || c->tower2_on) PAAC_CHECK_HIP(hipMalloc(&c->tower_pack, tower_pack_bytes()));
     PAAC_CHECK_HIP(hipMalloc(&c->fc_pack, (size_t)c->spec.flat * c->spec.fc * sizeof(float)));
   }
   c->ev_start = new hipEvent_t[paac_ctx::PROF_MAX_EVENTS];
@@ -229,6 +234,7 @@ int paac_destroy(paac_ctx* c) {
   float* bufs[] = {c->dh, c->wslab, c->partials, c->dl_buf, c->zeros};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
+  if (c->mt_ahead) (void)hipFree(c->mt_ahead);
   if (c->tower_pack) (void)hipFree(c->tower_pack);
   if (c->fc_pack) (void)hipFree(c->fc_pack);
   for (int i = 0; i < paac_ctx::PROF_MAX_EVENTS; ++i) {
@@ -344,15 +350,37 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
                      int32_t* actions, float* probs_out, float* values_out, uint64_t env_seed, uint32_t env_offset,
                      uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset, uint8_t* stack_out,
                      uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
-                     void* finished, uint8_t* raw_scratch, paac_stream_t stream) {
+                     void* finished, uint8_t* raw_scratch, void* walk_scratch, int64_t walk_scratch_bytes,
+                     paac_stream_t stream) {
   PAAC_REQUIRE(ctx && params && states && mt_state && actions && probs_out && values_out && stack_out && rewards_out &&
                masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
-  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS,
-               "paac_act_step_mt: batch %d outside (0, min(max_batch=%d, %d)]", batch, ctx->max_batch, PAAC_ACT_STEP_MAX_ENVS);
-  PAAC_REQUIRE((int64_t)batch * (ctx->cfg.num_actions - 1) <= 1024,
-               "paac_act_step_mt: N*(A-1) = %ld exceeds 1024 (use paac_forward + paac_sample_mt_synth_step)",
-               (long)batch * (ctx->cfg.num_actions - 1));
+  PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS_LARGE,
+               "paac_act_step_mt: batch %d outside (0, min(max_batch=%d, %d)]", batch, ctx->max_batch,
+               PAAC_ACT_STEP_MAX_ENVS_LARGE);
+  PAAC_REQUIRE((int64_t)batch * (ctx->cfg.num_actions - 1) <= PAAC_FUSED_SAMPLE_MAX_DRAWS,
+               "paac_act_step_mt: N*(A-1) = %ld exceeds %d (use paac_forward + paac_sample_mt + paac_synth_step)",
+               (long)batch * (ctx->cfg.num_actions - 1), PAAC_FUSED_SAMPLE_MAX_DRAWS);
   PAAC_REQUIRE(states != stack_out && states != stack_out2, "paac_act_step_mt: the step cannot shift the stacks in place");
+  if (batch > PAAC_ACT_STEP_MAX_ENVS || (int64_t)batch * (ctx->cfg.num_actions - 1) > 1024) {
+    // the large shards (128 x 18, 256 x 4): policy forward with its heads finish, then the sampler + environment-step launch
+    // with the walks spread over several workgroups -- whose MT19937 doubles a spare workgroup of the fc launch makes
+    // meanwhile (csrc/mt_ahead.h)
+    const bool tail = (ctx->tower_on || ctx->tower2_on) && ctx->managed_weights && batch <= PAAC_ACT_STEP_MAX_ENVS_LARGE;
+    if (tail) {
+      ctx->ahead_state = mt_state;
+      ctx->ahead_D = batch * (ctx->cfg.num_actions - 1);
+    }
+    int rc = launch_forward(ctx, 0, params, states, batch, nullptr, probs_out, values_out, (hipStream_t)stream);
+    ctx->ahead_state = nullptr;
+    if (rc) return rc;
+    rc = launch_sample_mt_synth_step(probs_out, ctx->cfg.num_actions, mt_state, actions, env_seed, env_offset, batch,
+                                     terminal_threshold, step_base_dev, step_offset, states, stack_out, stack_out2, rewards_out,
+                                     masks_out, ep_reward, ep_len, finished, walk_scratch, walk_scratch_bytes, raw_scratch,
+                                     tail ? ctx->mt_ahead : nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    PAAC_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const float *partial, *ba, *bc;
   int ntiles;
   int rc = launch_forward_trunk(ctx, params, states, batch, &partial, &ntiles, &ba, &bc, (hipStream_t)stream);

@@ -127,12 +127,17 @@ struct paac_ctx {
   int keep_row;
   int heads_pending_h;             // 1: the pending "slab" holds finished fc activations (bias + ReLU applied), one split
   float* zeros;                    // max(H) zero floats (the bias of heads that read finished activations)
+  // csrc/mt_ahead.h: the record a spare workgroup of the acting forward's fc launch leaves for the sampling step behind it
+  void* mt_ahead;                  // MtAhead, owned by the ctx
+  const uint32_t* ahead_state;     // one shot, set by paac_act_step_mt: the MT19937 state to work ahead from (nullptr: off)
+  int ahead_D;                     // doubles the step can consume at most: N * (A - 1)
   float* dl_buf;                   // [max_batch][kDlStride] per-row head gradients + loss terms (heads.h)
   int fc_splits_max;
   // conv tower (csrc/tower.h, Nature only): conv weights pre-split into bf16 planes in MFMA operand order
   void* tower_pack;      // kTowerPackVecs x 16 bytes, nullptr when the tower is off
   void* fc_pack;         // fc weights in fc_heads_kernel's fragment order (flat * H floats)
   int tower_on;          // PAAC_TOWER (default 1)
+  int tower2_on;         // the two-conv tower of the stock NIPS geometry (csrc/tower2.h), same knob
   int managed_weights;   // paac_set_managed_weights: 1 = the caller keeps tower_pack current (paac_clip_rmsprop / paac_pack_weights
                          // re-pack) and acting forwards keep no conv1 / conv2 activations; 0 = every forward re-packs first
   // profiling hooks
@@ -214,6 +219,13 @@ int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t
                                void* finished, hipStream_t s);
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s);
 int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s);
+size_t mt_ahead_bytes();
+bool tower2_available();
+int launch_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed, uint32_t env_offset,
+                                int N, uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset,
+                                const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards_out,
+                                float* masks_out, float* ep_reward, int32_t* ep_len, void* finished, void* walk_scratch,
+                                int64_t walk_scratch_bytes, uint8_t* raw_scratch, const void* mt_ahead, hipStream_t stream);
 int launch_bootstrap_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, int train_row, hipStream_t s);
 int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, const float** partial,
                          int* ntiles, const float** ba, const float** bc, hipStream_t s);

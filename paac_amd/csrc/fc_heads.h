@@ -16,6 +16,7 @@
 // group, identically for both operands, like dmm.h).
 #pragma once
 #include "dmm.h"
+#include "mt_ahead.h"
 
 namespace paac {
 
@@ -48,9 +49,16 @@ template <int K, int H, int NW, bool A_PACKED>
 __global__ __launch_bounds__(64 * NW) void fc_heads_kernel(const float* __restrict__ act, const f32x4* __restrict__ wfp,
                                                            const float* __restrict__ bf, const float* __restrict__ Wa,
                                                            const float* __restrict__ Wc, const int A, const int B,
-                                                           float* __restrict__ partial, float* __restrict__ h_out) {
+                                                           float* __restrict__ partial, float* __restrict__ h_out,
+                                                           const MtAheadArgs ahead) {
   constexpr int NTILES = H / 16, G = K / 16, GPW = G / NW, PF = 8;
   static_assert(K % 16 == 0 && H % 16 == 0 && G % NW == 0 && GPW > PF, "fc geometry");
+  if (ahead.out != nullptr && blockIdx.x == gridDim.x - 1) {
+    // the spare workgroup (csrc/mt_ahead.h): the doubles of the sampling step that follows this forward
+    __shared__ uint32_t ahead_blocks[MT_AHEAD_BLK * 624];
+    mt_produce_ahead<64 * NW>(ahead, ahead_blocks);
+    return;
+  }
   __shared__ f32x4 red[NW * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -143,24 +143,13 @@ __global__ void sample_philox_kernel(const float* __restrict__ probs, int N, int
 // =============================================================================================
 // numpy-parity sampler: legacy MT19937 multinomial(1, p - epsneg) per env, ONE serial stream
 // (paac.py:34-45; restated in oracle/sampler.py:sample_mt_restated).
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-  y ^= (y >> 11);
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= (y >> 18);
-  return y;
-}
-__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
-  const uint32_t yy = (a & 0x80000000u) | (b & 0x7fffffffu);
-  return (yy >> 1) ^ ((yy & 1u) ? 0x9908b0dfu : 0u);
-}
+// (mt_temper / mt_mix: csrc/mt_ahead.h)
 
 // scratch layout (bytes): pj f64[N*(A-1)] | U f64[N*(A-1)] | blocks u32[nblk*624]
 // LDSC > 0 (N*(A-1) <= mt_lds_d(LDSC)): the three work arrays live in LDS instead of the global scratch.
 // LDS size classes of the sampler body: 0 = work arrays in the global scratch, 1 = small (the 32..64-environment shards),
 // 2 = large (256 environments x 4 actions, 128 x 18: one workgroup with most of the CU's LDS)
-constexpr int MT_LDS_D = 1024;            // class 1: draws (N * (A - 1)) the LDS arrays hold
-constexpr int MT_LDS_D2 = 2304;           // class 2
+// (MT_LDS_D = 1024 draws for class 1, MT_LDS_D2 = 2304 for class 2: csrc/mt_ahead.h)
 constexpr int MT_TAB_MAX = 16384;         // class 1: entries of the first-hit table
 constexpr int MT_TAB_MAX2 = 66560;        // class 2: 256 environments x 3 draws -> 65,536 + 256 entries
 __host__ __device__ constexpr int mt_lds_d(int cls) { return cls == 2 ? MT_LDS_D2 : (cls == 1 ? MT_LDS_D : 1); }
@@ -465,6 +454,24 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
 // probs_hook (with probs_lds): produces the probabilities in probs_lds and ends with a barrier.  It is called AFTER the
 // state blocks and the doubles (which need nothing but the state words) so that whatever the hook waits on -- the loads
 // of the head partials it requested earlier -- travels while those phases compute.
+// Phase 1 of sample_mt_body for one (environment, category j): the row's first j + 1 probabilities requested at once (one
+// LDS round trip instead of j dependent ones), then the reference's sequential fp64 subtraction order over the first j of
+// them (paac.py:42: p - epsneg in float32; numpy's multinomial: remaining -= p_i in float64).
+template <int R>
+__device__ __forceinline__ void mt_row_inputs(const float* row_p, const int j, double& remaining, double& p) {
+  float row[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) row[i] = row_p[i <= j ? i : j];
+  remaining = 1.0;
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (i < j) remaining -= (double)(row[i] - 5.9604644775390625e-08f);
+  float pj_f = row[0];
+#pragma unroll
+  for (int i = 1; i < R; ++i) pj_f = (i == j) ? row[i] : pj_f;
+  p = (double)(pj_f - 5.9604644775390625e-08f);
+}
+
 struct NoProbsHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -474,7 +481,8 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
                                                double* __restrict__ u_g, uint32_t* __restrict__ blocks_g,
                                                int32_t* __restrict__ actions, int16_t* act_lds,
                                                const float* probs_lds = nullptr, const uint32_t* stw_pre = nullptr,
-                                               const HOOK probs_hook = HOOK(), const MultiWalk mw = MultiWalk{nullptr, nullptr, nullptr, 0}) {
+                                               const HOOK probs_hook = HOOK(), const MultiWalk mw = MultiWalk{nullptr, nullptr, nullptr, 0},
+                                               const MtAhead* __restrict__ ahead = nullptr) {
   constexpr bool HOOKED = !__is_same(HOOK, NoProbsHook);
   MISC_STAMP(0);
   constexpr bool LDSPATH = LDSC > 0;
@@ -493,12 +501,26 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   __shared__ int any_zero;       // some conditional probability is exactly 0 (the table chase needs none); later
                                  // reused for the consumed-draw count
   uint32_t pos;
+  // csrc/mt_ahead.h (class 2 only): the step's doubles, made one launch ahead, travel with the state words and the
+  // probabilities; they are used only if their key matches the stream state found here (pre_ok, uniform)
+  constexpr int AHW = LDSC == 2 ? (MT_LDS_D2 + 255) / 256 : 1;
+  double ahu[AHW];
+  uint32_t ahk[5] = {0u, 0u, 0u, 0u, 0u};
+  bool pre_ok = false;
   if (tid == 0) any_zero = 0;    // ordered before phase 1 by the barrier below (LDSPATH) / after phase 2's copy
   if constexpr (LDSPATH) {
     // ONE memory round trip: the 625 state words and the N*A probabilities are all requested before anything
     // is consumed (unrolled, clamped indices), then parked in LDS.
     uint32_t stw[3];
     float prw[PRW];
+    if constexpr (LDSC == 2) {
+      if (ahead) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ahk[k] = ahead->hdr[k];
+#pragma unroll
+        for (int k = 0; k < AHW; ++k) ahu[k] = ahead->u[min(tid + k * 256, MT_LDS_D2 - 1)];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) stw[k] = stw_pre ? stw_pre[k] : mt_state[min(tid + k * 256, 624)];
     if (!probs_lds) {
@@ -518,6 +540,16 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     }
     __syncthreads();
     pos = pos_s;
+    if constexpr (LDSC == 2) {
+      if (ahead) {
+        pre_ok = ahk[0] == pos && ahk[1] == blocks[0] && ahk[2] == blocks[1] && ahk[3] == blocks[623] && (int)ahk[4] >= N * J;
+        if (pre_ok) {
+#pragma unroll
+          for (int k = 0; k < AHW; ++k)
+            if (tid + k * 256 < N * J) u_buf[tid + k * 256] = ahu[k];
+        }
+      }
+    }
   } else {
     pos = mt_state[624];
   }
@@ -538,9 +570,14 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     for (int d = e_lo * J + tid; d < e_hi * J; d += 256) {
       const int e = d / J, j = d - e * J;
       double remaining = 1.0;
-      for (int i = 0; i < j; ++i)
-        remaining -= (double)(pr[(long)e * A + i] - 5.9604644775390625e-08f);   // float32 arithmetic, paac.py:42
-      const double p = (double)(pr[(long)e * A + j] - 5.9604644775390625e-08f);
+      double p;
+      if (LDSPATH && J <= 4) mt_row_inputs<4>(pr + (long)e * A, j, remaining, p);
+      else if (LDSPATH && J <= 17) mt_row_inputs<17>(pr + (long)e * A, j, remaining, p);
+      else {
+        for (int i = 0; i < j; ++i)
+          remaining -= (double)(pr[(long)e * A + i] - 5.9604644775390625e-08f);
+        p = (double)(pr[(long)e * A + j] - 5.9604644775390625e-08f);
+      }
       const double cond = p / remaining;
       pj_buf[d] = cond;
       if (LDSPATH && cond == 0.0) any_zero = 1;
@@ -577,7 +614,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     for (int i = tid; i < 624; i += 256) blocks[i] = mt_state[i];
   }
   __syncthreads();
-  for (int b = 1; b < nblk; ++b) {
+  for (int b = 1; b < (pre_ok ? 1 : nblk); ++b) {      // (pre_ok: blocks and doubles came ready-made)
     const uint32_t* o = blocks + (long)(b - 1) * 624;
     uint32_t* nw = blocks + (long)b * 624;
     for (int k = tid; k < 227; k += 256) nw[k] = o[k + 397] ^ mt_mix(o[k], o[k + 1]);
@@ -585,13 +622,12 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     for (int k = 227 + tid; k < 454; k += 256) nw[k] = nw[k - 227] ^ mt_mix(o[k], o[k + 1]);
     __syncthreads();
     for (int k = 454 + tid; k < 623; k += 256) nw[k] = nw[k - 227] ^ mt_mix(o[k], o[k + 1]);
-    __syncthreads();
-    if (tid == 0) nw[623] = nw[396] ^ mt_mix(o[623], nw[0]);
+    if (tid == 255) nw[623] = nw[396] ^ mt_mix(o[623], nw[0]);      // both inputs are older than this pass
     __syncthreads();
   }
   MISC_STAMP(3);
   // phase 3: the 53-bit doubles numpy would draw, in stream order
-  for (int d = tid; d < D; d += 256) {
+  for (int d = tid; d < (pre_ok ? 0 : D); d += 256) {
     const uint32_t q = pos + 2u * (uint32_t)d;
     const uint32_t a = mt_temper(blocks[q]) >> 5;
     const uint32_t b = mt_temper(blocks[q + 1]) >> 6;
@@ -815,8 +851,13 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       fb -= 1;
       np = 624;
     }
-    if (fb > 0)
-      for (int i = lane; i < 624; i += 64) mt_state[i] = blocks[(long)fb * 624 + i];
+    if (fb > 0) {
+      if (pre_ok) {       // the blocks stayed in the record that came with the doubles
+        for (int i = lane; i < 624; i += 64) mt_state[i] = ahead->blocks[(long)fb * 624 + i];
+      } else {
+        for (int i = lane; i < 624; i += 64) mt_state[i] = blocks[(long)fb * 624 + i];
+      }
+    }
     if (lane == 0) mt_state[624] = np;
   }
   return true;
@@ -964,7 +1005,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
                                                               uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                               float* masks_out, float* ep_reward, int32_t* ep_len,
                                                               FinishedRing* fin, const MultiWalk mw,
-                                                              uint32_t* __restrict__ raw) {
+                                                              uint32_t* __restrict__ raw, const MtAhead* __restrict__ ahead) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   const int samplers = mw.W > 0 ? mw.W : 1;          // sampler workgroups in front of the shift workgroups
   if ((int)blockIdx.x < samplers) {
@@ -975,7 +1016,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     const int32_t ep_len0 = ep_len[e0];
     // (ends past a barrier; with several sampler workgroups only the one that finishes the walks goes on)
     if (!sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, nullptr, nullptr, NoProbsHook(),
-                              mw))
+                              mw, ahead))
       return;
     MISC_STAMP(7);
     for (int e = threadIdx.x; e < N; e += 256) {
@@ -1494,7 +1535,7 @@ static void fill_pack_spec(const paac_ctx* ctx, PackSpec* pk, int* fc_tiles, int
   *conv_tiles = 0;
   long owned_begin[4], owned_end[4];   // float ranges the tile blocks own, ascending
   int nowned = 0;
-  if (ctx->tower_on && ctx->tower_pack) {
+  if ((ctx->tower_on || ctx->tower2_on) && ctx->tower_pack) {
     pk->nconv = sp.nconv;
     long dst = 0;
     for (int i = 0; i < sp.nconv; ++i) {
@@ -1742,6 +1783,22 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
                               uint64_t step_offset, const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2,
                               float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len, void* finished,
                               void* walk_scratch, int64_t walk_scratch_bytes, uint8_t* raw_scratch, paac_stream_t stream) {
+  return launch_sample_mt_synth_step(probs, A, mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev,
+                                     step_offset, stack_in, stack_out, stack_out2, rewards_out, masks_out, ep_reward, ep_len,
+                                     finished, walk_scratch, walk_scratch_bytes, raw_scratch, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace paac {
+size_t mt_ahead_bytes() { return sizeof(MtAhead); }
+
+// mt_ahead (nullable): the record a spare workgroup of the preceding fc launch left (csrc/mt_ahead.h)
+int launch_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed, uint32_t env_offset,
+                                int N, uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset,
+                                const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards_out,
+                                float* masks_out, float* ep_reward, int32_t* ep_len, void* finished, void* walk_scratch,
+                                int64_t walk_scratch_bytes, uint8_t* raw_scratch, const void* mt_ahead, hipStream_t stream) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
   PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D2, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
                "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D2);
@@ -1773,17 +1830,20 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
     launch_k(synth_step_a_mt_kernel<2>, dim3(samplers + nshift), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
              mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
-             (uint32_t*)raw_scratch);
+             (uint32_t*)raw_scratch, reinterpret_cast<const MtAhead*>(mt_ahead));
   else
     launch_k(synth_step_a_mt_kernel<1>, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
              actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
-             (uint32_t*)raw_scratch);
+             (uint32_t*)raw_scratch, (const MtAhead*)nullptr);
   }
   if (raw_scratch) launch_preprocess_after_step(raw_scratch, N, stack_in, stack_out, stack_out2, masks_out, (hipStream_t)stream);
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace paac
+
+extern "C" {
 
 int paac_clip_rmsprop(paac_ctx* ctx, float* params, const float* grad, float* ms, float* mom, int64_t n,
                       const float* lr_dev, float decay, float momentum, float eps, float clip_norm, int clip_mode,

@@ -5,6 +5,7 @@
 // (networks.py:6-9) -- so every weight tensor is already the row-major [K,N] B-matrix of its GEMM.
 #include "net_common.h"
 #include "tower.h"
+#include "tower2.h"
 #include "fc_heads.h"
 #include "gemm3.h"
 
@@ -114,7 +115,10 @@ static int launch_fc_gemm3(const float* x, const float* wf, float* slab, int bat
 
 // ---------------------------------------------------------------------------------------------
 // Conv tower (tower.h): Nature conv1 -> conv2 -> conv3 in one launch.
-size_t tower_pack_bytes() { return (size_t)kTowerPackAllVecs * sizeof(bf16x8); }
+size_t tower_pack_bytes() { return (size_t)kTowerPackAllVecs * sizeof(bf16x8); }      // (the two-conv tower's planes fit too)
+// the two-conv tower is written for the stock NIPS geometry (16 / 32 filters, fc 256)
+constexpr bool kTower2 = OtherNet::NCONV == 2 && OtherNet::C1 == 16 && OtherNet::C2 == 32 && OtherNet::FLAT == kT2Flat;
+bool tower2_available() { return kTower2; }
 
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
   const paac_layout& L = ctx->layout;
@@ -127,6 +131,12 @@ int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s) {
     else
       launch_k(pack_fc_kernel<OtherNet::FLAT, OtherNet::H>, dim3((OtherNet::FLAT / 16) * (OtherNet::H / 16) * 64 / 256), dim3(256),
                s, PROF_NONE, wf, out);
+  }
+  if (ctx->tower2_on) {
+    constexpr int threads2 = (8 * 1 + 8 * 2) * 64;
+    launch_k(pack_tower2_kernel, dim3((threads2 + 255) / 256), dim3(256), s, PROF_NONE, params + L.offset[0], params + L.offset[2],
+             reinterpret_cast<bf16x8*>(ctx->tower_pack));
+    return 0;
   }
   if (!ctx->tower_on) return 0;
   constexpr int threads = (8 * 2 + 16 * 4 + 18 * 4) * 64;
@@ -193,6 +203,48 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
   }
 }
 
+template <class G, bool KEEP>
+static void launch_tower2_variant(const Tower2Args& a, hipStream_t s) {
+  launch_k(tower2_kernel<G, KEEP>, dim3((unsigned)(a.batch * G::NR)), dim3(512), s, PROF_WHOLE, a);
+}
+
+// The two-conv tower (tower2.h): same roles of keep / packed / keepW as launch_tower's.
+static void launch_tower2(paac_ctx* ctx, Workspace& W, const float* params, const uint8_t* states, int batch, bool keep,
+                          bool packed2, hipStream_t s, Workspace* keepW = nullptr, int keep_row = 0) {
+  const paac_layout& L = ctx->layout;
+  Tower2Args a;
+  a.states = states;
+  const bf16x8* pk = reinterpret_cast<const bf16x8*>(ctx->tower_pack);
+  a.w1p = pk;
+  a.w2p = pk + kT2W1Vecs;
+  a.b1 = params + L.offset[1];
+  a.b2 = params + L.offset[3];
+  a.act1 = W.act[0];
+  a.act2 = W.act[1];
+  a.batch = batch;
+  a.act2_packed = packed2 ? 1 : 0;
+  a.act2_rows = nullptr;
+  if (keepW) {
+    keep = true;
+    a.act1 = keepW->act[0] + (size_t)keep_row * 400 * 16;
+    a.act2_rows = keepW->act[1] + (size_t)keep_row * kT2Flat;
+  }
+  const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
+  // regions per sample: nine 3x3 regions while that stays near one round of the 256 CUs, four 5x5 up to 72 rows, else one
+  int regions = (9 * batch <= 320) ? 9 : (4 * batch <= 288) ? 4 : 1;
+  if (force == 1 || force == 4 || force == 9) regions = force;
+  if (regions == 9) {
+    if (keep) launch_tower2_variant<Tower2Geom<3, 3>, true>(a, s);
+    else launch_tower2_variant<Tower2Geom<3, 3>, false>(a, s);
+  } else if (regions == 4) {
+    if (keep) launch_tower2_variant<Tower2Geom<5, 5>, true>(a, s);
+    else launch_tower2_variant<Tower2Geom<5, 5>, false>(a, s);
+  } else {
+    if (keep) launch_tower2_variant<Tower2Geom<9, 9>, true>(a, s);
+    else launch_tower2_variant<Tower2Geom<9, 9>, false>(a, s);
+  }
+}
+
 template <class NT>
 static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8_t* states, int batch, float* logits,
                         float* probs, float* values, const PhiloxArgs& ph, const SynthStepArgs& st, hipStream_t s,
@@ -222,6 +274,8 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
 
   bool tower = false;
   if constexpr (NT::NCONV == 3) tower = ctx->tower_on != 0;
+  bool tower2 = false;                       // the two-conv network's tower (tower2.h)
+  if constexpr (NT::NCONV == 2 && kTower2) tower2 = ctx->tower2_on != 0;
   // paac_keep_next_forward (one shot): this acting forward's rows are also kept in the training activation set
   int keep_row = -1;
   if (wsi == 0) {
@@ -234,11 +288,11 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   // is rounded up at allocation)
   // ... and acting batches of up to 256 rows (the 128- / 256-environment shards) take the same fc kernel, finished by a
   // few workgroups (heads_finish_rows_kernel) instead of split-K slabs + a per-row heads launch
-  const bool mid_tail = !small_tail && tower && !keep_acts && wsi == 0 && batch <= kFcHeadsMidRows && !ph.enabled &&
+  const bool mid_tail = !small_tail && (tower || tower2) && !keep_acts && wsi == 0 && batch <= kFcHeadsMidRows && !ph.enabled &&
                         !st.enabled && !trunk_only;
   Workspace* keepW = nullptr;
   if (keep_row >= 0) {
-    if (!(tower && !keep_acts && (small_tail || mid_tail) && keep_row + batch <= ctx->max_batch)) {
+    if (!((tower || tower2) && !keep_acts && (small_tail || mid_tail) && keep_row + batch <= ctx->max_batch)) {
       set_error("paac_keep_next_forward: rows [%d, %d) cannot be kept -- needs the three-conv network's tower, managed weights, an "
                 "acting forward of at most %d rows and keep_row + batch <= max_batch (%d)", keep_row, keep_row + batch,
                 kFcHeadsMidRows, ctx->max_batch);
@@ -247,20 +301,26 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     keepW = &ctx->ws[1];
   }
   // (measured at 128 rows: fragment-order hand-off tower 16.5 + fc 8.7 us, plain rows 15.2 + 10.4)
-  const bool packed3 = tower && (small_tail || mid_tail) && !keep_acts;
-  if (!ctx->managed_weights && (tower || batch <= kFcHeadsMaxRows)) launch_pack_weights(ctx, params, s);
+  const bool packed3 = (tower || tower2) && (small_tail || mid_tail) && !keep_acts;
+  if (!ctx->managed_weights && (tower || tower2 || batch <= kFcHeadsMaxRows)) launch_pack_weights(ctx, params, s);
   if (tower) {
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
     prof_mix(3);       // conv1: u8 pixels x weights split into 3 bf16 terms
     prof_mix(6);       // conv2, conv3: six-product split-bf16
     launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s, keepW, keep_row < 0 ? 0 : keep_row);
   }
-  if (!tower) {
+  if (tower2) {
+    ProfScope ps(ctx, F_CONV_TOWER, batch, s);
+    prof_mix(3);       // conv1: u8 pixels x weights split into 3 bf16 terms
+    prof_mix(6);       // conv2: six-product split-bf16
+    launch_tower2(ctx, W, params, states, batch, keep_acts, packed3, s, keepW, keep_row < 0 ? 0 : keep_row);
+  }
+  if (!tower && !tower2) {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
     GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)256 * NT::C1 * 4, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
     launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
   }
-  if (!tower) {
+  if (!tower && !tower2) {
     ProfScope ps(ctx, F_CONV2_FWD, batch, s);
     GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
     launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
@@ -288,13 +348,17 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
       ProfScope ps(ctx, F_FC_FWD, batch, s);
       prof_mix(1);     // fp32 MFMA
       constexpr int NW = (NT::FLAT / 16) % 7 == 0 ? 7 : 9;      // waves per workgroup: divides the K groups evenly
+      // one-shot (paac_act_step_mt): a spare workgroup makes the next sampling step's MT19937 doubles meanwhile (mt_ahead.h)
+      MtAheadArgs ah{ctx->ahead_state, ctx->ahead_state ? reinterpret_cast<MtAhead*>(ctx->mt_ahead) : nullptr, ctx->ahead_D};
+      ctx->ahead_state = nullptr;
+      const unsigned grid = NTILES * ((batch + 15) / 16) + (ah.out ? 1 : 0);
       if (packed3)
-        launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, true>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,
-                 last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, h_keep);
+        launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, true>, dim3(grid), dim3(64 * NW), s, PROF_WHOLE,
+                 last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, h_keep, ah);
       else
-        launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, false>, dim3(NTILES * ((batch + 15) / 16)), dim3(64 * NW), s, PROF_WHOLE,
+        launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, false>, dim3(grid), dim3(64 * NW), s, PROF_WHOLE,
                  last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial,
-                 keep_h ? W.h : (float*)nullptr);
+                 keep_h ? W.h : (float*)nullptr, ah);
     }
     if (defer_heads) return 0;       // the caller's launch finishes the heads (or, for bootstrap rows, the backward's)
     if (mid_tail) {

@@ -210,13 +210,13 @@ class Context(object):
 
     def act_step_mt(self, params, states, mt_state, actions, probs_out, values_out, env_seed, env_offset,
                     terminal_threshold, step_base_dev, step_offset, stack_out, rewards_out, masks_out, ep_reward, ep_len,
-                    finished=None, stack_out2=None, raw_scratch=None):
+                    finished=None, stack_out2=None, raw_scratch=None, walk_scratch=None):
         """One acting step in three launches: policy forward, then heads finish + numpy-parity sampler + synthetic
         environment step in one (include/paac_hip.h: paac_act_step_mt).  raw_scratch ([N,2,210,160] u8): path B -- the
         step launch writes the raw screen pairs, a fourth launch (max, PIL-nearest resize, history push) builds the stacks."""
         N, A = self._check_states(states), self.num_actions
-        if N > ACT_STEP_MAX_ENVS or N * (A - 1) > ACT_STEP_MAX_DRAWS:
-            raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS, ACT_STEP_MAX_DRAWS))
+        if N > ACT_STEP_MAX_ENVS_LARGE or N * (A - 1) > FUSED_SAMPLE_MAX_DRAWS:
+            raise ValueError("act_step_mt supports N <= %d and N*(A-1) <= %d" % (ACT_STEP_MAX_ENVS_LARGE, FUSED_SAMPLE_MAX_DRAWS))
         if tuple(stack_out.shape) != (N,) + OBS_SHAPE:
             raise ValueError("stack_out must be [%d,84,84,4], got %s" % (N, tuple(stack_out.shape)))
         if states.data_ptr() == stack_out.data_ptr() or (stack_out2 is not None and states.data_ptr() == stack_out2.data_ptr()):
@@ -234,7 +234,9 @@ class Context(object):
             _ptr(masks_out, torch.float32, N, "masks_out"), _ptr(ep_reward, torch.float32, N, "ep_reward"),
             _ptr(ep_len, torch.int32, N, "ep_len"),
             ctypes.c_void_p(finished.data_ptr()) if finished is not None else ctypes.c_void_p(0),
-            _ptr(raw_scratch, torch.uint8, N * 2 * RAW_H * RAW_W, "raw_scratch", True), _stream()),
+            _ptr(raw_scratch, torch.uint8, N * 2 * RAW_H * RAW_W, "raw_scratch", True),
+            ctypes.c_void_p(walk_scratch.data_ptr()) if walk_scratch is not None else ctypes.c_void_p(0),
+            int(walk_scratch.numel()) if walk_scratch is not None else 0, _stream()),
             "paac_act_step_mt")
 
     def pack_weights(self, params):
@@ -424,6 +426,7 @@ def synth_step(seed, env_offset, actions, terminal_threshold, step_base_dev, ste
 FUSED_SAMPLE_MAX_DRAWS = 2304
 ACT_STEP_MAX_DRAWS = 1024
 ACT_STEP_MAX_ENVS = 64
+ACT_STEP_MAX_ENVS_LARGE = 256    # paac_act_step_mt's four-launch form (large shards)
 KEEP_FORWARD_MAX_ROWS = 256      # paac_keep_next_forward: acting forwards of up to this many rows (csrc/fc_heads.h)
 
 

@@ -100,9 +100,13 @@ class DeviceRollout(object):
         # else does).  Acting step t keeps its rows at [t*N, (t+1)*N) of the training activation set, the N bootstrap
         # observations (paac.py:140-142) run as one acting-shaped forward into rows [T*N, (T+1)*N), and the backward starts
         # from there.  PAAC_REUSE_ACTING=0 restores the recomputed training forward (both routes are tested).
+        # PAAC_MT_AHEAD=0: the large shards' step as paac_forward + paac_sample_mt_synth_step (every sampler workgroup rebuilds
+        # the MT19937 blocks and doubles itself)
+        # (the fused conv launches -- csrc/tower.h, csrc/tower2.h -- exist for the reference's two stock trunks)
+        towered = getattr(L.network, "ARCH", None) in ("NATURE", "NIPS") and os.environ.get("PAAC_TOWER", "1") != "0"
+        self.act_step_large = os.environ.get("PAAC_MT_AHEAD", "1") != "0" and N <= hip_ops.ACT_STEP_MAX_ENVS_LARGE and towered
         self.reuse_acting = (os.environ.get("PAAC_REUSE_ACTING", "1") != "0" and sampler == "numpy"
-                             and len(L.network.layout["tensors"]) == 12 and os.environ.get("PAAC_TOWER", "1") != "0"
-                             and N <= hip_ops.KEEP_FORWARD_MAX_ROWS)
+                             and towered and N <= hip_ops.KEEP_FORWARD_MAX_ROWS)
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
         torch.cuda.synchronize(dev)
 
@@ -129,12 +133,14 @@ class DeviceRollout(object):
             # (path B -- self.raw -- rides the same fused launches: they write the raw screen pairs instead of shifting the
             # stacks and the preprocess launch follows)
             fused = self.sampler == "numpy" and N * (self.A - 1) <= hip_ops.FUSED_SAMPLE_MAX_DRAWS
-            if fused and N <= hip_ops.ACT_STEP_MAX_ENVS and N * (self.A - 1) <= hip_ops.ACT_STEP_MAX_DRAWS:
-                # the whole step in three launches: conv tower, fc + head partials, heads finish + sampler + env step
+            if fused and (self.act_step_large or (N <= hip_ops.ACT_STEP_MAX_ENVS and N * (self.A - 1) <= hip_ops.ACT_STEP_MAX_DRAWS)):
+                # the whole step in three launches: conv tower, fc + head partials, heads finish + sampler + env step -- or, for
+                # the large shards, four (heads finish on its own; the sampler's MT19937 doubles made meanwhile by a spare
+                # workgroup of the fc launch)
                 L.ctx.act_step_mt(params, st[t], self.mt_state, self.actions[t], self.probs, self.values[t],
                                   self.env_spec["seed"], self.env_offset, self.env_spec["terminal_threshold"], self.tick, t,
                                   st[t + 1], self.rewards[t], self.masks[t], self.ep_reward, self.ep_len, self.finished,
-                                  stack_out2=wrap, raw_scratch=self.raw)
+                                  stack_out2=wrap, raw_scratch=self.raw, walk_scratch=self.walk_scratch)
                 continue
             if fused:
                 # numpy-parity sampler and env step in one launch (the frame shift does not need the action)

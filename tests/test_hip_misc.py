@@ -258,7 +258,10 @@ def test_synthetic_env_matches_host_spec(raw_frames):
 
 
 @pytest.mark.parametrize("managed", [False, True])
-@pytest.mark.parametrize("arch,A,N", [("NATURE", 4, 32), ("NATURE", 6, 33), ("NIPS", 18, 16), ("NATURE", 18, 60)])
+@pytest.mark.parametrize("arch,A,N", [("NATURE", 4, 32), ("NATURE", 6, 33), ("NIPS", 18, 16), ("NATURE", 18, 60),
+                                      # the large shards (four launches; managed: the sampler's MT19937 doubles come from the
+                                      # spare workgroup of the fc launch, csrc/mt_ahead.h): configs[4] and configs[2] per GPU
+                                      ("NATURE", 18, 128), ("NATURE", 4, 256), ("NATURE", 9, 100)])
 def test_act_step_equals_separate_calls(arch, A, N, managed):
     """paac_act_step_mt (forward with the head contractions in the fc epilogue, then heads finish + MT19937 sampler +
     synthetic env step in ONE launch) == paac_forward + paac_sample_mt + paac_synth_step, bit for bit, over consecutive
@@ -293,9 +296,16 @@ def test_act_step_equals_separate_calls(arch, A, N, managed):
 
     a, b = fresh(), fresh()
     scratch = hip_ops.sample_mt_scratch(N, A, "cuda")
+    walk = hip_ops.walk_scratch(N, A, "cuda") if N > hip_ops.ACT_STEP_MAX_ENVS else None
     for step in range(8):
+        if step == 5 and walk is not None:
+            # the stream moves between two steps (someone else drew from np.random): the next step's record is made from
+            # the state it finds, whatever the previous step left (unmanaged contexts make no record: every sampler
+            # workgroup builds its own blocks and doubles there)
+            for d in (a, b):
+                hip_ops.sample_mt(d["probs"], d["mt"], scratch, d["act"])
         ctx.act_step_mt(p, a["s0"], a["mt"], a["act"], a["probs"], a["val"], env_seed, off, thr, a["tick"], 0, a["s1"],
-                        a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"])
+                        a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"], walk_scratch=walk)
         ctx.forward(p, b["s0"], probs=b["probs"], values=b["val"])
         hip_ops.sample_mt(b["probs"], b["mt"], scratch, b["act"])
         hip_ops.synth_step(env_seed, off, b["act"], thr, b["tick"], 0, b["s0"], b["s1"], b["rew"], b["msk"], b["ep_r"],

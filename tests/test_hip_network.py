@@ -662,8 +662,10 @@ def test_profiling_hooks_name_the_launches_and_their_instruction_mix():
     ctx.close()
 
 
-@pytest.mark.parametrize("A,T,N,scale", [(4, 5, 32, 1.0), (4, 5, 32, TRAINED), (18, 3, 128, 1.0), (6, 2, 7, 1.0), (4, 2, 256, TRAINED)])
-def test_update_from_kept_acting_rows(A, T, N, scale):
+@pytest.mark.parametrize("arch,A,T,N,scale", [("NATURE", 4, 5, 32, 1.0), ("NATURE", 4, 5, 32, TRAINED), ("NATURE", 18, 3, 128, 1.0),
+                                              ("NATURE", 6, 2, 7, 1.0), ("NATURE", 4, 2, 256, TRAINED),
+                                              ("NIPS", 6, 5, 32, 1.0), ("NIPS", 6, 5, 8, TRAINED), ("NIPS", 4, 2, 100, 1.0)])
+def test_update_from_kept_acting_rows(arch, A, T, N, scale):
     """paac_keep_next_forward + paac_bootstrap_forward_trunk: the T acting forwards keep their rows in the training activation
     set, the bootstrap observations run as one acting-shaped forward, and the backward starts from there -- no training
     forward (weights are frozen inside a cycle: paac.py:105 and :163-165 evaluate the same network on the same
@@ -671,8 +673,8 @@ def test_update_from_kept_acting_rows(A, T, N, scale):
     order; against the float64 oracle: activations of the kept rows, gradient within the usual bars."""
     from paac_amd import hip_ops, _lib
     B = T * N
-    params, states, idx, _, _ = make_case("NATURE", A, B + N, seed=41, weight_scale=scale)
-    ctx = hip_ops.Context(ARCH_ID["NATURE"], A, max_batch=B + N)
+    params, states, idx, _, _ = make_case(arch, A, B + N, seed=41, weight_scale=scale)
+    ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B + N)
     p = upload_params(ctx, params)
     ctx.set_managed_weights(True)
     ctx.pack_weights(p)
@@ -703,7 +705,8 @@ def test_update_from_kept_acting_rows(A, T, N, scale):
         ctx.clip_rmsprop(q, grad, ms, mom, torch.tensor([0.01], device="cuda"), 0.99, 0.0, 0.1, 3.0, _lib.CLIP_GLOBAL, gnorm_out=gn)
         ctx.pack_weights(p)                          # the optimizer step re-packed q's weights: back to p's for the next route
         torch.cuda.synchronize()
-        acts_kept = [ctx.debug_activation(i, B + N).cpu().numpy() for i in (1, 2, 3, 4)] if kept else None
+        layers = (1, 2, 3, 4) if arch == "NATURE" else (1, 2, 4)
+        acts_kept = [ctx.debug_activation(i, B + N).cpu().numpy() for i in layers] if kept else None
         out.append(dict(grad=grad.cpu().numpy(), y=y.cpu().numpy(), adv=adv.cpu().numpy(), loss=loss.cpu().numpy(),
                         gn=float(gn.item()), values=values.cpu().numpy(), acts=acts_kept))
     a, b = out
@@ -714,15 +717,67 @@ def test_update_from_kept_acting_rows(A, T, N, scale):
     assert abs(a["gn"] - b["gn"]) <= 1e-5 * a["gn"]
     assert np.abs(a["loss"] - b["loss"]).max() <= 1e-5 * max(1.0, np.abs(a["loss"]).max())
     # the kept rows against the oracle
-    ref = onet.forward(params, states, "NATURE", dtype=np.float64, keep=True)["cache"]
-    for i, got in zip((1, 2, 3, 4), b["acts"]):
+    ref = onet.forward(params, states, arch, dtype=np.float64, keep=True)["cache"]
+    H = 512 if arch == "NATURE" else 256
+    for i, got in zip(layers, b["acts"]):
         want = ref["a%d" % i if i < 4 else "h"].reshape(-1)
         assert got.shape == want.shape
         if i == 4:          # fc activations: the update's B rows (the bootstrap rows' stay in the kept slab, read for v only)
-            got, want = got[:B * 512], want[:B * 512]
+            got, want = got[:B * H], want[:B * H]
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), "kept layer %d" % i
     # a forward that cannot keep its rows says so
     ctx.keep_next_forward(B)                        # rows [B, B + N + 1) do not fit the training set
     with pytest.raises(Exception):
         ctx.forward(p, s[:N + 1], values=torch.zeros(N + 1, device="cuda"))
+    ctx.close()
+
+
+@pytest.mark.parametrize("regions", [9, 4, 1])
+@pytest.mark.parametrize("B,A,scale", [(5, 6, 1.0), (33, 4, 1.0), (32, 6, SATURATED), (160, 6, TRAINED)])
+def test_conv_tower2_variants(regions, B, A, scale, monkeypatch):
+    """csrc/tower2.h: the reference's DEFAULT architecture (networks.py:138-151, NIPS) with conv1 -> conv2 in one launch, in
+    each of its region layouts (nine 3x3 regions, four 5x5, one workgroup per sample), against the float64 oracle --
+    activations, logits, values -- and against the per-layer kernels (PAAC_TOWER=0: the same arithmetic in another order);
+    then the managed (acting) mode: fragment-order hand-off to the fc kernel, same bits."""
+    from paac_amd import _lib, hip_ops
+    params, states, idx, y, adv = make_case("NIPS", A, B, seed=13, weight_scale=scale)
+    ctx = hip_ops.Context(ARCH_ID["NIPS"], A, max_batch=B)
+    for cls in (0, 1, 2):
+        _lib.check(ctx.lib.paac_debug_set_tuning(ctx.handle, 11, cls, regions, 0, -1), "set_tuning")
+    p = upload_params(ctx, params)
+    s = torch.from_numpy(states).cuda()
+    logits = torch.zeros((B, A), device="cuda")
+    values = torch.zeros((B,), device="cuda")
+    ctx.prof_enable(True)
+    ctx.forward(p, s, logits=logits, values=values)
+    torch.cuda.synchronize()
+    fams = [name for name, batch, ms, mix in ctx.prof_read(with_mix=True)]
+    ctx.prof_enable(False)
+    assert "conv_tower" in fams and "conv1_fwd" not in fams and "conv2_fwd" not in fams
+    ref = onet.forward(params, states, "NIPS", dtype=np.float64, keep=True)
+    check_activations(ctx, ref["cache"], "NIPS", B, scale)
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert np.abs(values.cpu().numpy() - ref["v"]).max() < 1e-4
+    # the per-layer route (what NIPS ran on before): same values to fp32 summation order
+    monkeypatch.setenv("PAAC_TOWER", "0")
+    plain = hip_ops.Context(ARCH_ID["NIPS"], A, max_batch=B)
+    monkeypatch.delenv("PAAC_TOWER")
+    logits0 = torch.zeros((B, A), device="cuda")
+    plain.prof_enable(True)
+    plain.forward(p, s, logits=logits0)
+    torch.cuda.synchronize()
+    assert "conv1_fwd" in [name for name, batch, ms, mix in plain.prof_read(with_mix=True)]
+    plain.prof_enable(False)
+    assert float((logits - logits0).abs().max()) < 2e-5 * max(1.0, float(logits.abs().max()))
+    plain.close()
+    # managed mode: the acting forward keeps only conv2's output, in the fc kernel's fragment order
+    ctx.set_managed_weights(True)
+    ctx.pack_weights(p)
+    logits2 = torch.zeros((B, A), device="cuda")
+    ctx.forward(p, s, logits=logits2)
+    torch.cuda.synchronize()
+    if B <= 64:
+        assert torch.equal(logits, logits2)
+    else:       # up to 256 rows the managed forward takes the acting fc kernel, the unmanaged one the split-K GEMM
+        assert float((logits - logits2).abs().max()) < 2e-5 * max(1.0, float(logits.abs().max()))
     ctx.close()

@@ -20,6 +20,15 @@ rew = torch.zeros(N, device=dev); msk = torch.zeros(N, device=dev); epr = torch.
 epl = torch.zeros(N, dtype=torch.int32, device=dev); fin = torch.zeros(hip_ops.FINISHED_RING_BYTES // 4, dtype=torch.int32, device=dev)
 tick = torch.zeros(1, dtype=torch.int64, device=dev)
 walk = hip_ops.walk_scratch(N, A, dev) if os.environ.get("PROBE_MULTI", "") == "1" else None
+# PROBE_ACT=1: through paac_act_step_mt (the large shards' sampler then finds its doubles made ahead, csrc/mt_ahead.h)
+ctx = None
+if os.environ.get("PROBE_ACT", "") == "1":
+    ctx = hip_ops.Context(1, A, max_batch=N)
+    params = torch.randn(ctx.layout["total"], device=dev) * 0.02
+    ctx.set_managed_weights(os.environ.get("PROBE_MANAGED", "1") == "1")
+    ctx.pack_weights(params)
+    val = torch.zeros(N, device=dev)
+    pr_out = torch.zeros((N, A), device=dev)
 names = ["entry->loads landed", "phase 1 (cond. probabilities)", "phase 2 (state blocks)", "phase 3 (doubles)",
          "table fill", "chase", "write-back", "bookkeeping"]
 acc = np.zeros(8)
@@ -27,8 +36,12 @@ reps = 50
 for r in range(reps + 5):
     probs = torch.softmax(torch.randn(N, A, device=dev), dim=1)    # cold-ish probabilities each time
     torch.cuda.synchronize()
-    hip_ops.sample_mt_synth_step(probs, mt, act, 3, 0, terminal_threshold(0.01), tick, 0, s0, s1, rew, msk, epr, epl, fin,
-                                 walk_scratch=walk)
+    if ctx is not None:
+        ctx.act_step_mt(params, s0, mt, act, pr_out, val, 3, 0, terminal_threshold(0.01), tick, 0, s1, rew, msk, epr, epl, fin,
+                        walk_scratch=walk)
+    else:
+        hip_ops.sample_mt_synth_step(probs, mt, act, 3, 0, terminal_threshold(0.01), tick, 0, s0, s1, rew, msk, epr, epl, fin,
+                                     walk_scratch=walk)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().astype(np.float64)
     if r >= 5:
