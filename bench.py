@@ -309,13 +309,15 @@ def main():
         try:
             import glob
             cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_by_family.json")))
-            if cand:
-                tj = json.load(open(cand[-1]))
-                key = "%s[batch=%d]" % (dom["kernel"], dom["batch"])
-                if tj.get("workload", "").split(", sampler")[0] == ("%s action set (A=%d), %s net, %d envs per GPU x 1 GPU, t_max=%d, %s" % (
-                        a.game, A, a.arch, N, T, "raw 210x160 frame pairs + GPU max/resize/stack" if a.raw_frames else
-                        "synthetic 84x84x4 u8 frames generated on device")):
-                    traffic = tj["bytes_per_launch"].get(key)
+            key = "%s[batch=%d]" % (dom["kernel"], dom["batch"])
+            want = "%s action set (A=%d), %s net, %d envs per GPU x 1 GPU, t_max=%d, %s" % (
+                a.game, A, a.arch, N, T, "raw 210x160 frame pairs + GPU max/resize/stack" if a.raw_frames else
+                "synthetic 84x84x4 u8 frames generated on device")
+            for path in reversed(cand):               # the latest round's table taken on this workload
+                tj = json.load(open(path))
+                if tj.get("workload", "").split(", sampler")[0] == want and key in tj["bytes_per_launch"]:
+                    traffic = tj["bytes_per_launch"][key]
+                    break
         except Exception:
             traffic = None
         if dom["unit"] == "TFLOP/s":

@@ -383,12 +383,25 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
   }
   const float *partial, *ba, *bc;
   int ntiles;
+  // Up to 64 environments the sampler's state blocks and doubles already hide behind the loads of the head partials
+  // (misc.hip: synth_step_a_mth_kernel): making them one launch ahead (csrc/mt_ahead.h) measured SLOWER here -- 658 k against
+  // 669 k env-steps/s at the headline shape, the extra loads sit at the head of the sampler workgroup's chain --, so it is off
+  // unless PAAC_MT_AHEAD_SMALL=1 asks for it.  The large shards (above) use it.
+  static const bool ahead_on = [] {
+    const char* v = getenv("PAAC_MT_AHEAD_SMALL");
+    return v && *v && atoi(v) != 0;
+  }();
+  if (ahead_on) {
+    ctx->ahead_state = mt_state;
+    ctx->ahead_D = batch * (ctx->cfg.num_actions - 1);
+  }
   int rc = launch_forward_trunk(ctx, params, states, batch, &partial, &ntiles, &ba, &bc, (hipStream_t)stream);
+  ctx->ahead_state = nullptr;
   if (rc) return rc;
   rc = launch_sample_env_step_heads(partial, ntiles, ba, bc, probs_out, values_out, ctx->cfg.num_actions, mt_state, actions,
                                     env_seed, env_offset, batch, terminal_threshold, step_base_dev, step_offset, states,
                                     stack_out, stack_out2, rewards_out, masks_out, ep_reward, ep_len, finished, raw_scratch,
-                                    (hipStream_t)stream);
+                                    ahead_on ? ctx->mt_ahead : nullptr, (hipStream_t)stream);
   if (rc) return rc;
   PAAC_CHECK_HIP(hipGetLastError());
   return 0;

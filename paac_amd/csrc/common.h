@@ -234,7 +234,7 @@ int launch_sample_env_step_heads(const float* partial, int ntiles, const float* 
                                  uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
                                  const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
                                  float* masks, float* ep_reward, int32_t* ep_len, void* finished, uint8_t* raw_scratch,
-                                 hipStream_t s);
+                                 const void* mt_ahead, hipStream_t s);
 int launch_backward(paac_ctx* ctx, const float* params, const uint8_t* states, const int32_t* actions, const float* y,
                     const float* adv, int batch, float beta, float* grad, float* loss_out, int phase, hipStream_t s,
                     const paac_returns* ret = nullptr);

@@ -481,10 +481,17 @@ __global__ __launch_bounds__(256) void heads_train_kernel(const float* __restric
 #pragma unroll
   for (int jj = 0; jj < JPT; ++jj) {
     const int j = tid + jj * 256;
+    if (splits == 1) {         // one slab (rows kept by the acting forwards, or an unsplit fc layer): one load, not eight
+      sv[jj][0] = slab[(long)i * H + j];
+      sb[jj][0] = slab[(long)ib * H + j];
 #pragma unroll
-    for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) {
-      sv[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)i * H + j];
-      sb[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)ib * H + j];
+      for (int sp = 1; sp < FC_SPLITS_MAX; ++sp) sv[jj][sp] = sb[jj][sp] = 0.f;
+    } else {
+#pragma unroll
+      for (int sp = 0; sp < FC_SPLITS_MAX; ++sp) {
+        sv[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)i * H + j];
+        sb[jj][sp] = slab[(sp < splits ? sp : 0) * slab_stride + (long)ib * H + j];
+      }
     }
     bj[jj] = fc_b[j];
     wcj[jj] = Wc[j];

@@ -239,6 +239,18 @@ __device__ __forceinline__ void mt_fill_table(const double* pj_buf, const double
   }
 }
 
+// Walk thresholds carry their sense in the sign bit: hit(U) == ((U > |t|) != signbit(t)) -- thresholds lie in [0, 1], so one
+// 8-byte LDS read per (environment, category) instead of a threshold and a flag (the walks are bound by the LDS instructions
+// they issue: 2 x J per hop instead of 3 x J).
+__device__ __forceinline__ double mt_pack_threshold(const double cond) {
+  const bool inv = !(cond <= 0.5);
+  const double thr = inv ? 1.0 - (1.0 - cond) : 1.0 - cond;
+  return inv ? __longlong_as_double(__double_as_longlong(thr) | (long long)0x8000000000000000ull) : thr;
+}
+__device__ __forceinline__ bool mt_hit(const double U, const double t) {
+  return (U > fabs(t)) != (__double_as_longlong(t) < 0);
+}
+
 // Small shards (up to 32 environments x up to 7 actions) without a table: the environments are cut into groups of QG (8,
 // or 4 where the walks still fit the workgroup); group k can be entered at k QG (J-1) + 1 stream offsets, and one THREAD
 // per (group, entry offset) walks its group from there, deciding each environment's first hit itself (J draws against
@@ -269,17 +281,15 @@ __device__ __forceinline__ void mt_group_walks(const double* thr_s, const double
     for (int hop = 0; hop < QG; ++hop) {
       if (e < N) {
         double U[JC], T[JC];
-        int I[JC];
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
           U[j] = u_buf[o + j < D ? o + j : D - 1];
           T[j] = thr_s[e * JC + j];
-          I[j] = inv_s[e * JC + j];
         }
         int jh = JC;
 #pragma unroll
         for (int j = JC - 1; j >= 0; --j)
-          if ((U[j] > T[j]) != (I[j] != 0)) jh = j;
+          if (mt_hit(U[j], T[j])) jh = j;
         act_h[tid * QG + hop] = (unsigned char)jh;
         o += (jh + 1 < JC) ? jh + 1 : JC;
         ++e;
@@ -340,17 +350,15 @@ __device__ __forceinline__ int mw_first_hit(const double* thr_s, const unsigned 
                                             const int o, const int D, const int Jdyn) {
   if constexpr (JC > 0) {
     double U[JC], T[JC];
-    int I[JC];
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
       U[j] = u_buf[o + j < D ? o + j : D - 1];
       T[j] = thr_s[e * JC + j];
-      I[j] = inv_s[e * JC + j];
     }
     int jh = JC;
 #pragma unroll
     for (int j = JC - 1; j >= 0; --j)
-      if ((U[j] > T[j]) != (I[j] != 0)) jh = j;
+      if (mt_hit(U[j], T[j])) jh = j;
     return jh;
   } else {
     const int J = Jdyn;
@@ -358,17 +366,15 @@ __device__ __forceinline__ int mw_first_hit(const double* thr_s, const unsigned 
     constexpr int CH = 6;                                // categories per round trip; a wave scans until its last walk has hit
     for (int j0 = 0; j0 < J && jh == J; j0 += CH) {
       double U[CH], T[CH];
-      int I[CH];
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         const int j = j0 + q < J ? j0 + q : J - 1;
         U[q] = u_buf[o + j < D ? o + j : D - 1];
         T[q] = thr_s[e * J + j];
-        I[q] = inv_s[e * J + j];
       }
 #pragma unroll
       for (int q = CH - 1; q >= 0; --q)
-        if (j0 + q < J && (U[q] > T[q]) != (I[q] != 0)) jh = j0 + q;
+        if (j0 + q < J && mt_hit(U[q], T[q])) jh = j0 + q;
     }
     return jh;
   }
@@ -503,7 +509,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   uint32_t pos;
   // csrc/mt_ahead.h (class 2 only): the step's doubles, made one launch ahead, travel with the state words and the
   // probabilities; they are used only if their key matches the stream state found here (pre_ok, uniform)
-  constexpr int AHW = LDSC == 2 ? (MT_LDS_D2 + 255) / 256 : 1;
+  constexpr int AHW = LDSC == 2 ? (MT_LDS_D2 + 255) / 256 : (LDSC == 1 ? MT_LDS_D / 256 : 1);
   double ahu[AHW];
   uint32_t ahk[5] = {0u, 0u, 0u, 0u, 0u};
   bool pre_ok = false;
@@ -513,13 +519,11 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     // is consumed (unrolled, clamped indices), then parked in LDS.
     uint32_t stw[3];
     float prw[PRW];
-    if constexpr (LDSC == 2) {
-      if (ahead) {
+    if (ahead) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) ahk[k] = ahead->hdr[k];
+      for (int k = 0; k < 5; ++k) ahk[k] = ahead->hdr[k];
 #pragma unroll
-        for (int k = 0; k < AHW; ++k) ahu[k] = ahead->u[min(tid + k * 256, MT_LDS_D2 - 1)];
-      }
+      for (int k = 0; k < AHW; ++k) ahu[k] = ahead->u[min(tid + k * 256, MT_LDS_D2 - 1)];
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) stw[k] = stw_pre ? stw_pre[k] : mt_state[min(tid + k * 256, 624)];
@@ -540,14 +544,12 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     }
     __syncthreads();
     pos = pos_s;
-    if constexpr (LDSC == 2) {
-      if (ahead) {
-        pre_ok = ahk[0] == pos && ahk[1] == blocks[0] && ahk[2] == blocks[1] && ahk[3] == blocks[623] && (int)ahk[4] >= N * J;
-        if (pre_ok) {
+    if (ahead) {
+      pre_ok = ahk[0] == pos && ahk[1] == blocks[0] && ahk[2] == blocks[1] && ahk[3] == blocks[623] && (int)ahk[4] >= N * J;
+      if (pre_ok) {
 #pragma unroll
-          for (int k = 0; k < AHW; ++k)
-            if (tid + k * 256 < N * J) u_buf[tid + k * 256] = ahu[k];
-        }
+        for (int k = 0; k < AHW; ++k)
+          if (tid + k * 256 < N * J) u_buf[tid + k * 256] = ahu[k];
       }
     }
   } else {
@@ -581,11 +583,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       const double cond = p / remaining;
       pj_buf[d] = cond;
       if (LDSPATH && cond == 0.0) any_zero = 1;
-      if (walk_ok) {                                     // hit(U) == ((U > thr) != inv), as mt_fill_table
-        const bool inv = !(cond <= 0.5);
-        thr_s[d] = inv ? 1.0 - (1.0 - cond) : 1.0 - cond;
-        inv_s[d] = inv ? 1 : 0;
-      }
+      if (walk_ok) thr_s[d] = mt_pack_threshold(cond);    // hit(U) == ((U > thr) != inv), as mt_fill_table
     }
   };
   // several sampler workgroups: each needs the thresholds of the environments ITS walks visit only; whether some
@@ -594,8 +592,15 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   if (multi) {
     // (the last category of a row is never drawn for; it is tested like the others -- a division per element costs more
     // than the serial path taken once in 2^24 rows for nothing)
-    for (int i = tid; i < N * A; i += 256)
-      if ((pr[i] - 5.9604644775390625e-08f) == 0.0f) any_zero = 1;
+    {
+      float pz[PRW];
+#pragma unroll
+      for (int k = 0; k < PRW; ++k) pz[k] = pr[min(tid + k * 256, N * A - 1)];     // N * A <= 2 D <= PRW * 256
+      bool z = false;
+#pragma unroll
+      for (int k = 0; k < PRW; ++k) z = z || ((pz[k] - 5.9604644775390625e-08f) == 0.0f);
+      if (z) any_zero = 1;
+    }
     const int NGm = (N + MW_G - 1) / MW_G;
     const long nwk = mw_first_walk(NGm, J - 1);
     const long w0 = (long)blockIdx.x * 256, w1 = w0 + 255 < nwk - 1 ? w0 + 255 : nwk - 1;
@@ -1057,7 +1062,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
                                                                uint32_t* __restrict__ stack_out,
                                                                uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                                float* masks_out, float* ep_reward, int32_t* ep_len,
-                                                               FinishedRing* fin, uint32_t* __restrict__ raw) {
+                                                               FinishedRing* fin, uint32_t* __restrict__ raw,
+                                                               const MtAhead* __restrict__ ahead) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   if (blockIdx.x == 0) {
     __shared__ int16_t act_s[kFcHeadsMaxRows];
@@ -1080,11 +1086,13 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
       float pv[32], bias;
       heads_partials_issue(partial, ntiles, N * (A + 1), A, ba, bc, pv, bias);
       auto finish_heads = [&]() { heads_from_issued(pv, bias, partial, ntiles, N, A, lg_s, probs_sh, probs_out, values_out); };
-      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, finish_heads);
+      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, finish_heads,
+                        MultiWalk{nullptr, nullptr, nullptr, 0}, ahead);
     } else {
       heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,
                           nullptr);
-      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw);
+      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, NoProbsHook(),
+                        MultiWalk{nullptr, nullptr, nullptr, 0}, ahead);
     }
     // (the sampler body ends past a barrier; its last wave is still writing the stream position back)
     if ((int)threadIdx.x < N)       // N <= 64 here: one environment per thread
@@ -1592,13 +1600,13 @@ int launch_sample_env_step_heads(const float* partial, int ntiles, const float* 
                                  uint32_t env_offset, int N, uint32_t thresh, const uint64_t* step_base, uint64_t step_off,
                                  const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards,
                                  float* masks, float* ep_reward, int32_t* ep_len, void* finished, uint8_t* raw_scratch,
-                                 hipStream_t s) {
+                                 const void* mt_ahead, hipStream_t s) {
   {
     ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, s);
     launch_k(synth_step_a_mth_kernel, dim3(1 + N * PRE_BANDS), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
              values_out, A, mt_state, actions, seed, env_offset, N, thresh, step_base, step_off, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished,
-             (uint32_t*)raw_scratch);
+             (uint32_t*)raw_scratch, reinterpret_cast<const MtAhead*>(mt_ahead));
   }
   if (raw_scratch) launch_preprocess_after_step(raw_scratch, N, stack_in, stack_out, stack_out2, masks, s);
   return 0;

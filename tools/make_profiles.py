@@ -134,6 +134,48 @@ json.dump({"workload": meta["config"]["workload"], "bytes_per_launch": fam,
                      "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B); average per launch"},
           open("profiles/%s_traffic_by_family.json" % tag, "w"), indent=1)
 
+# 2c. BASELINE configs[2]'s raw-frame path (256 environments, raw 210x160 screen pairs -> preprocess kernel): kernel stats of
+# its own rocprofv3 run, PMC traffic of its own passes, and the per-family table bench.py looks up for that workload
+try:
+    rstats = glob.glob(os.path.join(src, "stats_raw256", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(rstats, "profiles/%s_raw256_rocprofv3_kernel_stats.csv" % tag)
+
+    def pmc_dir(name, counter):
+        f = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            k = (short(r['Kernel_Name']), r.get('Grid_Size', ''))
+            agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
+        return agg
+    rfe, rwr = pmc_dir("pmc_fetch_raw256", "FETCH_SIZE"), pmc_dir("pmc_write_raw256", "WRITE_SIZE")
+    rtraffic = {}
+    with open("profiles/%s_raw256_pmc_traffic.csv" % tag, "w") as f:
+        f.write("kernel,grid_size,launches,FETCH_SIZE_KB_raw_per_launch,fetch_bytes_corrected_x2,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch\n")
+        for k in sorted(rfe, key=lambda k: -rfe[k][0]):
+            fk = rfe[k][0] / rfe[k][1]
+            wk = rwr.get(k, [0, 1])[0] / max(1, rwr.get(k, [0, 1])[1])
+            rtraffic[k] = (2 * fk + wk) * 1024
+            f.write("\"%s\",%s,%d,%.1f,%.0f,%.1f,%.0f\n" % (k[0], k[1], rfe[k][1], fk, 2 * fk * 1024, wk, rtraffic[k]))
+    rmeta = json.loads(open(os.path.join(src, "bench_256envs_raw.json")).read().strip().splitlines()[-1])
+    rn = rmeta["config"]["envs_per_gpu"]
+    rfam = {}
+    for name, pat in (("preprocess_stack", "preprocess_stack_kernel"), ("sample_env_step", "synth_step_a_mt_kernel"),
+                      ("env_step", "synth_raw_kernel"), ("fc_fwd", "fc_heads_kernel"), ("heads_fwd", "heads_finish_rows_kernel")):
+        ks = [k for k in rtraffic if pat in k[0]]
+        if ks:
+            rfam["%s[batch=%d]" % (name, rn)] = max(rtraffic[k] for k in ks)
+    ks = sorted([k for k in rtraffic if "tower_kernel<TowerGeom" in k[0]], key=lambda k: rtraffic[k])
+    for k, bb in zip(ks, [rn, rn * (rmeta["config"]["t_max"] + 1)]):
+        rfam["conv_tower[batch=%d]" % bb] = rtraffic[k]
+    json.dump({"workload": rmeta["config"]["workload"], "bytes_per_launch": rfam,
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py --envs 256 --raw-frames; "
+                         "(2*FETCH_SIZE + WRITE_SIZE)*1024; average per launch"},
+              open("profiles/%s_raw256_traffic_by_family.json" % tag, "w"), indent=1)
+except (IndexError, KeyError, FileNotFoundError) as exc:
+    print("no raw-frame passes:", exc)
+
 # 3. bench lines + tuner log
 for name in sorted(os.path.basename(f) for f in glob.glob(os.path.join(src, "bench_*.json"))) + ["tune_gemm.txt"]:
     p = os.path.join(src, name)
