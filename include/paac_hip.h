@@ -308,6 +308,11 @@ int paac_graph_destroy(paac_graph* g);
  * last (acting or training); 11..13 / 14 = the gradients wrt them.  Returns the element count. */
 int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream);
 
+/* Test/debug: sampler workgroup `sampler_workgroup` of paac_act_step_mt's large-shard step launch reports an exactly-zero
+ * conditional probability it has not seen (-1: off, the default) -- exercises the rare serial path of the distributed zero
+ * detection on ordinary probabilities.  Process-wide; synchronises the device. */
+int paac_debug_report_zero(int sampler_workgroup);
+
 /* Tuning (tools/tune_gemm.py): override the launch configuration of GEMM op `op` (0 conv1_fwd, 1 conv2_fwd,
  * 2 conv3_fwd, 3 fc_fwd, 4 fc_wgrad, 5 fc_dgrad, 6 conv3_wgrad, 7 conv3_dgrad, 8 conv2_wgrad, 9 conv2_dgrad,
  * 10 conv1_wgrad, 11 conv tower: cfg = regions per sample, 1 / 2 / 4, -1 = by batch) for batch class 0 (batch <= 64), 1 (batch <= 512) or 2: cfg = index into the family's configuration table

@@ -84,6 +84,7 @@ _SIGNATURES = {
                                  c_uint32, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "paac_walk_scratch_bytes": (c_int64, [c_int, c_int]),
+    "paac_debug_report_zero": (c_int, [c_int]),
     "paac_sample_mt_synth_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_uint32, c_int, c_uint32, c_void_p,
                                           c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -370,13 +370,28 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
       ctx->ahead_state = mt_state;
       ctx->ahead_D = batch * (ctx->cfg.num_actions - 1);
     }
-    int rc = launch_forward(ctx, 0, params, states, batch, nullptr, probs_out, values_out, (hipStream_t)stream);
+    // (three launches when the walks can be spread -- walk_scratch lent -- and the action set is small: the sampler workgroups
+    // then also finish the heads of the environments they visit, from the fc kernel's per-tile partials.  Measured: 256 x 4
+    // 16.2 + 4.3 us -> 18.7 us per step, 1.898 -> 1.927 M env-steps/s; 128 x 18: 18.4 + 4.5 -> 24.0 us, SLOWER -- up to 24
+    // rows x 19 outputs x 32 partials and an 18-way softmax at the head of every sampler workgroup's chain cost more than the
+    // launch they replace -- so the fold is taken up to 8 actions.  PAAC_HEADS_IN_SAMPLER=0 / =1 force it off / on.)
+    static const int fold_knob = [] {
+      const char* v = getenv("PAAC_HEADS_IN_SAMPLER");
+      return (v && *v) ? (atoi(v) != 0 ? 1 : 0) : -1;
+    }();
+    const bool fold = fold_knob >= 0 ? fold_knob == 1 : ctx->cfg.num_actions <= 8;
+    HeadsPartials hp{nullptr, 0, nullptr, nullptr, values_out};
+    int rc;
+    if (tail && fold && sampler_folds_heads(batch, ctx->cfg.num_actions, walk_scratch))
+      rc = launch_forward_trunk(ctx, params, states, batch, &hp.partial, &hp.ntiles, &hp.ba, &hp.bc, (hipStream_t)stream);
+    else
+      rc = launch_forward(ctx, 0, params, states, batch, nullptr, probs_out, values_out, (hipStream_t)stream);
     ctx->ahead_state = nullptr;
     if (rc) return rc;
     rc = launch_sample_mt_synth_step(probs_out, ctx->cfg.num_actions, mt_state, actions, env_seed, env_offset, batch,
                                      terminal_threshold, step_base_dev, step_offset, states, stack_out, stack_out2, rewards_out,
                                      masks_out, ep_reward, ep_len, finished, walk_scratch, walk_scratch_bytes, raw_scratch,
-                                     tail ? ctx->mt_ahead : nullptr, (hipStream_t)stream);
+                                     tail ? ctx->mt_ahead : nullptr, (hipStream_t)stream, hp.partial ? &hp : nullptr);
     if (rc) return rc;
     PAAC_CHECK_HIP(hipGetLastError());
     return 0;

@@ -219,13 +219,22 @@ int launch_forward_sample_step(paac_ctx* ctx, const float* params, const uint8_t
                                void* finished, hipStream_t s);
 int launch_pack_weights(paac_ctx* ctx, const float* params, hipStream_t s);
 int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s);
+// the fc kernel's per-tile head partials of an acting forward whose heads a later launch finishes (csrc/fc_heads.h)
+struct HeadsPartials {
+  const float* partial;
+  int ntiles;
+  const float *ba, *bc;
+  float* values_out;
+};
 size_t mt_ahead_bytes();
+bool sampler_folds_heads(int N, int A, const void* walk_scratch);
 bool tower2_available();
 int launch_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed, uint32_t env_offset,
                                 int N, uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset,
                                 const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards_out,
                                 float* masks_out, float* ep_reward, int32_t* ep_len, void* finished, void* walk_scratch,
-                                int64_t walk_scratch_bytes, uint8_t* raw_scratch, const void* mt_ahead, hipStream_t stream);
+                                int64_t walk_scratch_bytes, uint8_t* raw_scratch, const void* mt_ahead, hipStream_t stream,
+                                const HeadsPartials* heads = nullptr);
 int launch_bootstrap_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, int train_row, hipStream_t s);
 int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* states, int batch, const float** partial,
                          int* ntiles, const float** ba, const float** bc, hipStream_t s);

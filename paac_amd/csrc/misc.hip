@@ -380,12 +380,16 @@ __device__ __forceinline__ int mw_first_hit(const double* thr_s, const unsigned 
   }
 }
 
-// Returns true in the workgroup that took the last ticket (actions written, *used_s = draws consumed), false elsewhere.
+// Returns 1 in the workgroup that took the last ticket (actions written, *used_s = draws consumed), 0 elsewhere.
+// dist_zero: every workgroup has seen only ITS environments' probabilities (the heads were finished inside this launch) and
+// reports an exactly-zero conditional probability among them with its ticket -- the count rides in the upper half of the
+// ticket word, one atomic --; the last-ticket workgroup then returns 2 WITHOUT following the walks when any workgroup
+// reported one (the caller takes the serial path over all environments).
 template <int JC>
-__device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double* thr_s, const unsigned char* inv_s,
-                                               const double* u_buf, unsigned short* exits_lds, int* entry_s, int* used_s,
-                                               const int N, const int J, const int D, int32_t* __restrict__ actions,
-                                               int16_t* act_lds) {
+__device__ __forceinline__ int mt_multi_walks(const MultiWalk mw, const double* thr_s, const unsigned char* inv_s,
+                                              const double* u_buf, unsigned short* exits_lds, int* entry_s, int* used_s,
+                                              const int N, const int J, const int D, int32_t* __restrict__ actions,
+                                              int16_t* act_lds, const bool dist_zero = false, const bool local_zero = false) {
   const int tid = threadIdx.x;
   const int c1 = J - 1, NG = (N + MW_G - 1) / MW_G;
   const long nwk = mw_first_walk(NG, c1);
@@ -418,14 +422,17 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
   __shared__ int last_s;
   if (tid == 0) {
     __threadfence();
-    last_s = atomicAdd(mw.counter, 1u) == (unsigned int)(mw.W - 1);
+    const unsigned int add = 1u + ((dist_zero && local_zero) ? 0x10000u : 0u);
+    const unsigned int old = atomicAdd(mw.counter, add);
+    last_s = (old & 0xFFFFu) == (unsigned int)(mw.W - 1) ? (((old + add) >> 16) != 0u ? 2 : 1) : 0;
     if (last_s) {
       __threadfence();
       __hip_atomic_store(mw.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
-  if (!last_s) return false;
+  if (!last_s) return 0;
+  if (last_s == 2) return 2;
   MISC_STAMP(10);
   {
     const uint4* src = reinterpret_cast<const uint4*>(mw.exits);       // 8 exit offsets per load (the scratch is padded)
@@ -452,7 +459,7 @@ __device__ __forceinline__ bool mt_multi_walks(const MultiWalk mw, const double*
     if (act_lds) act_lds[e] = (int16_t)jh;
   }
   __syncthreads();
-  return true;
+  return 1;
 }
 
 // probs_lds (LDSC > 0 only, nullable): the probabilities are already in LDS (written by this workgroup, barrier passed);
@@ -478,9 +485,47 @@ __device__ __forceinline__ void mt_row_inputs(const float* row_p, const int j, d
   p = (double)(pj_f - 5.9604644775390625e-08f);
 }
 
+// A probabilities hook: operator()(dst, scratch, lo, hi) leaves the probabilities of environments [lo, hi) at
+// dst[e * A + a] (dst = the body's LDS array unless the hook has its own; scratch = LDS free at that point) and ends with a
+// barrier; kOwnRows: the hook serves only the rows asked for (the multi-workgroup sampler: every workgroup finishes the heads
+// of ITS environments), so the exact-zero scan is distributed (mt_multi_walks: dist_zero).
 struct NoProbsHook {
   __device__ __forceinline__ void operator()() const {}
 };
+// test hook (paac_debug_report_zero): sampler workgroup `g_dbg_zero_wg` of the heads-folding launch reports an exactly-zero
+// conditional probability it has not seen, so that the protocol around it (count in the ticket word, the last-ticket
+// workgroup finishing all heads and walking serially) runs on ordinary probabilities; -1 = off
+__device__ int g_dbg_zero_wg = -1;
+// The multi-workgroup sampler's hook (class 2): finishes the heads of environments [lo, hi) from the fc kernel's per-tile
+// partials (csrc/fc_heads.h: the same sums in the same order as heads_from_partials), probabilities to dst[e * A + a] in LDS
+// and -- with the values -- to global memory; ends with a barrier.  scratch: (hi - lo) * (A + 1) floats of LDS.
+struct RowsHeadsHook {
+  const float* partial;
+  int ntiles, N, A;
+  const float *ba, *bc;
+  float *probs_out, *values_out;
+  __device__ __forceinline__ void operator()(float* dst, float* scratch, const int lo, const int hi) const {
+    const int tid = threadIdx.x;
+    const int n_total = N * (A + 1), n = (hi - lo) * (A + 1);
+    for (int i = tid; i < n; i += 256) {
+      const int a = i % (A + 1);
+      float acc = (a < A) ? ba[a] : bc[0];
+      for (int t0 = 0; t0 < ntiles; t0 += 32) {
+        float v[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t0 + t < ntiles ? t0 + t : 0) * n_total + (size_t)lo * (A + 1) + i];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) acc += (t0 + t < ntiles) ? v[t] : 0.f;
+      }
+      scratch[i] = acc;
+    }
+    __syncthreads();
+    heads_softmax_store(hi - lo, A, scratch, dst + (size_t)lo * A, nullptr, probs_out + (size_t)lo * A, values_out + lo, nullptr,
+                        nullptr, nullptr);
+  }
+};
+template <class H> struct HookOwnRows { static constexpr bool value = false; };
+template <> struct HookOwnRows<RowsHeadsHook> { static constexpr bool value = true; };
 template <int LDSC, class HOOK = NoProbsHook>
 __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
@@ -490,6 +535,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
                                                const HOOK probs_hook = HOOK(), const MultiWalk mw = MultiWalk{nullptr, nullptr, nullptr, 0},
                                                const MtAhead* __restrict__ ahead = nullptr) {
   constexpr bool HOOKED = !__is_same(HOOK, NoProbsHook);
+  constexpr bool OWNROWS = HookOwnRows<HOOK>::value;      // the hook finishes the heads of this workgroup's environments only
   MISC_STAMP(0);
   constexpr bool LDSPATH = LDSC > 0;
   constexpr int PRW = LDSC == 2 ? 18 : 8;             // probability floats per thread of the one-round-trip load
@@ -527,7 +573,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) stw[k] = stw_pre ? stw_pre[k] : mt_state[min(tid + k * 256, 624)];
-    if (!probs_lds) {
+    if (!probs_lds && !OWNROWS) {
 #pragma unroll
       for (int k = 0; k < PRW; ++k) prw[k] = probs[min(tid + k * 256, N * A - 1)];
     }
@@ -537,7 +583,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       if (idx < 624) blocks[idx] = stw[k];
       if (idx == 624) pos_s = stw[k];
     }
-    if (!probs_lds) {
+    if (!probs_lds && !OWNROWS) {
 #pragma unroll
       for (int k = 0; k < PRW; ++k)
         if (tid + k * 256 < N * A) probs_s[tid + k * 256] = prw[k];
@@ -592,7 +638,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   if (multi) {
     // (the last category of a row is never drawn for; it is tested like the others -- a division per element costs more
     // than the serial path taken once in 2^24 rows for nothing)
-    {
+    if constexpr (!OWNROWS) {
       float pz[PRW];
 #pragma unroll
       for (int k = 0; k < PRW; ++k) pz[k] = pr[min(tid + k * 256, N * A - 1)];     // N * A <= 2 D <= PRW * 256
@@ -640,7 +686,15 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
   }
   __syncthreads();
   if constexpr (HOOKED) {
-    probs_hook();            // ends with a barrier: the probabilities are in LDS
+    if constexpr (OWNROWS) {
+      // the heads of this workgroup's environments (jh_tab is free until phase 1 parks the thresholds there), then the
+      // exact-zero scan over them: what it finds travels with the ticket (mt_multi_walks: dist_zero)
+      probs_hook(probs_s, reinterpret_cast<float*>(jh_tab), p1_lo, p1_hi);
+      for (int i = p1_lo * A + tid; i < p1_hi * A; i += 256)
+        if ((pr[i] - 5.9604644775390625e-08f) == 0.0f) any_zero = 1;
+    } else {
+      probs_hook();          // ends with a barrier: the probabilities are in LDS
+    }
     phase1(p1_lo, p1_hi);
     __syncthreads();
   }
@@ -658,28 +712,37 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
     bool walked = false;
     if constexpr (LDSC == 2) {
       if (multi) {
-        if (any_zero) {
+        if (!OWNROWS && any_zero) {
           if (blockIdx.x != 0) return false;          // the rare exact-zero case: workgroup 0 alone, the serial way
           phase1(0, N);
           __syncthreads();
         } else {
           unsigned short* exits_lds = reinterpret_cast<unsigned short*>(jh_tab + 9 * mt_lds_d(2));
           static_assert(mt_tab_max(2) >= 9 * MT_LDS_D2 + 2 * 16384, "exit offsets of up to 16 k walks next to the thresholds");
-          bool owner;
+          int owner;
+          const bool lz = OWNROWS && (any_zero != 0 || (int)blockIdx.x == g_dbg_zero_wg);
           switch (J) {
-            case 1: owner = mt_multi_walks<1>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
-            case 2: owner = mt_multi_walks<2>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
-            case 3: owner = mt_multi_walks<3>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
-            case 5: owner = mt_multi_walks<5>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+            case 1: owner = mt_multi_walks<1>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
+            case 2: owner = mt_multi_walks<2>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
+            case 3: owner = mt_multi_walks<3>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
+            case 5: owner = mt_multi_walks<5>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
             // the 9- and 18-action sets: every category of a hop requested at once -- ONE LDS round trip per hop instead of
             // up to three dependent chunks (a wave waits for its slowest lane anyway): walks 8.4 -> 3 us at 128 x 18
-            case 8: owner = mt_multi_walks<8>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
-            case 17: owner = mt_multi_walks<17>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
-            default: owner = mt_multi_walks<0>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds); break;
+            case 8: owner = mt_multi_walks<8>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
+            case 17: owner = mt_multi_walks<17>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
+            default: owner = mt_multi_walks<0>(mw, thr_s, inv_s, u_buf, exits_lds, entry_s, &any_zero, N, J, D, actions, act_lds, OWNROWS, lz); break;
           }
           if (!owner) return false;
-          walked = true;
-          chased = true;
+          if (owner == 2) {
+            // some workgroup met an exactly-zero conditional probability among its environments: this one (the last
+            // ticket) finishes ALL heads and walks the environments the serial way (phase 4b); the walks are discarded
+            if constexpr (OWNROWS) probs_hook(probs_s, reinterpret_cast<float*>(jh_tab), 0, N);
+            phase1(0, N);
+            __syncthreads();
+          } else {
+            walked = true;
+            chased = true;
+          }
         }
       }
     }
@@ -999,7 +1062,7 @@ __global__ __launch_bounds__(256) void synth_step_a_kernel(uint64_t seed, uint32
 // per time step instead of two.  LDSC = 2 (large shards: up to 2304 draws): the sampler workgroup takes most of a CU's LDS,
 // which every workgroup of the launch then reserves -- so the stacks are shifted by one workgroup per environment (all 7
 // bands) instead of one per band.
-template <int LDSC>
+template <int LDSC, bool FOLD = false>
 __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __restrict__ probs, int A,
                                                               uint32_t* __restrict__ mt_state,
                                                               int32_t* __restrict__ actions, uint64_t seed,
@@ -1010,7 +1073,8 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
                                                               uint32_t* __restrict__ stack_out2, float* rewards_out,
                                                               float* masks_out, float* ep_reward, int32_t* ep_len,
                                                               FinishedRing* fin, const MultiWalk mw,
-                                                              uint32_t* __restrict__ raw, const MtAhead* __restrict__ ahead) {
+                                                              uint32_t* __restrict__ raw, const MtAhead* __restrict__ ahead,
+                                                              const RowsHeadsHook hs) {
   const uint64_t id = (step_base ? *step_base : 0ull) + step_off + 1ull;
   const int samplers = mw.W > 0 ? mw.W : 1;          // sampler workgroups in front of the shift workgroups
   if ((int)blockIdx.x < samplers) {
@@ -1020,9 +1084,17 @@ __global__ __launch_bounds__(256) void synth_step_a_mt_kernel(const float* __res
     const float ep_reward0 = ep_reward[e0];
     const int32_t ep_len0 = ep_len[e0];
     // (ends past a barrier; with several sampler workgroups only the one that finishes the walks goes on)
-    if (!sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, nullptr, nullptr, NoProbsHook(),
-                              mw, ahead))
-      return;
+    // hs.partial: the heads were NOT finished by a launch of their own -- every sampler workgroup finishes those of the
+    // environments its walks visit (paac_act_step_mt, large shards); otherwise `probs` holds all of them
+    // (FOLD is a template argument: the two bodies' LDS arrays would otherwise both count against the workgroup)
+    bool go_on;
+    if constexpr (FOLD)
+      go_on = sample_mt_body<LDSC, RowsHeadsHook>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, nullptr, nullptr,
+                                                  hs, mw, ahead);
+    else
+      go_on = sample_mt_body<LDSC>(probs, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, nullptr, nullptr,
+                                   NoProbsHook(), mw, ahead);
+    if (!go_on) return;
     MISC_STAMP(7);
     for (int e = threadIdx.x; e < N; e += 256) {
       const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
@@ -1780,6 +1852,11 @@ int paac_synth_step(uint64_t seed, uint32_t env_offset, int N, const int32_t* ac
   return 0;
 }
 
+int paac_debug_report_zero(int sampler_workgroup) {
+  PAAC_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_zero_wg), &sampler_workgroup, sizeof(int)));
+  return 0;
+}
+
 int64_t paac_walk_scratch_bytes(int N, int A) {
   if (N <= 0 || A < 2) return 0;
   const long nwk = mw_walks(N, A);
@@ -1793,7 +1870,7 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
                               void* walk_scratch, int64_t walk_scratch_bytes, uint8_t* raw_scratch, paac_stream_t stream) {
   return launch_sample_mt_synth_step(probs, A, mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev,
                                      step_offset, stack_in, stack_out, stack_out2, rewards_out, masks_out, ep_reward, ep_len,
-                                     finished, walk_scratch, walk_scratch_bytes, raw_scratch, nullptr, (hipStream_t)stream);
+                                     finished, walk_scratch, walk_scratch_bytes, raw_scratch, nullptr, (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"
@@ -1801,22 +1878,35 @@ int paac_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int
 namespace paac {
 size_t mt_ahead_bytes() { return sizeof(MtAhead); }
 
+// the step launch of launch_sample_mt_synth_step is the large-LDS sampler with its walks spread over several workgroups:
+// only then can those workgroups finish the heads themselves (HeadsPartials)
+static bool sampler_is_large(int N, int A) {
+  return (int64_t)N * (A - 1) > MT_LDS_D || (long)N + (long)(A - 2) * N * (N - 1) / 2 > MT_TAB_MAX;
+}
+bool sampler_folds_heads(int N, int A, const void* walk_scratch) {
+  return sampler_is_large(N, A) && walk_scratch != nullptr && mw_walks(N, A) <= 16384 && N <= 256 && A <= 32;
+}
+
 // mt_ahead (nullable): the record a spare workgroup of the preceding fc launch left (csrc/mt_ahead.h)
 int launch_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, int32_t* actions, uint64_t seed, uint32_t env_offset,
                                 int N, uint32_t terminal_threshold, const uint64_t* step_base_dev, uint64_t step_offset,
                                 const uint8_t* stack_in, uint8_t* stack_out, uint8_t* stack_out2, float* rewards_out,
                                 float* masks_out, float* ep_reward, int32_t* ep_len, void* finished, void* walk_scratch,
-                                int64_t walk_scratch_bytes, uint8_t* raw_scratch, const void* mt_ahead, hipStream_t stream) {
+                                int64_t walk_scratch_bytes, uint8_t* raw_scratch, const void* mt_ahead, hipStream_t stream,
+                                const HeadsPartials* heads) {
   PAAC_REQUIRE(N > 0 && A >= 2 && A <= 32, "paac_sample_mt_synth_step: N=%d A=%d", N, A);
   PAAC_REQUIRE((int64_t)N * (A - 1) <= MT_LDS_D2, "paac_sample_mt_synth_step: N*(A-1)=%ld exceeds the fused kernel's limit %d "
                "(use paac_sample_mt + paac_synth_step)", (long)N * (A - 1), MT_LDS_D2);
   PAAC_REQUIRE(probs && mt_state && actions && stack_in && stack_out && rewards_out && masks_out && ep_reward && ep_len,
                "paac_sample_mt_synth_step: null argument");
+  RowsHeadsHook hs{nullptr, 0, N, A, nullptr, nullptr, nullptr, nullptr};
   {
   ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, (hipStream_t)stream);
   // small shards: the small-LDS sampler, one shift workgroup per band; beyond 1024 draws or 64 environments (where the
   // two-level chase needs the large first-hit table): the large-LDS sampler, one shift workgroup per environment
-  const bool large = (int64_t)N * (A - 1) > MT_LDS_D || (long)N + (long)(A - 2) * N * (N - 1) / 2 > MT_TAB_MAX;
+  const bool large = sampler_is_large(N, A);
+  PAAC_REQUIRE(!(heads && heads->partial) || sampler_folds_heads(N, A, walk_scratch),
+               "paac_sample_mt_synth_step: unfinished heads need the multi-workgroup sampler (N=%d A=%d)", N, A);
   MultiWalk mw{nullptr, nullptr, nullptr, 0};
   if (large && walk_scratch != nullptr) {
     // the caller lent a (zero-initialised, otherwise untouched) scratch: the walks go out over several workgroups
@@ -1831,19 +1921,26 @@ int launch_sample_mt_synth_step(const float* probs, int A, uint32_t* mt_state, i
       mw.W = (int)((nwk + 255) / 256);
     }
   }
+  if (heads && heads->partial && large)             // the sampler workgroups finish the heads themselves
+    hs = RowsHeadsHook{heads->partial, heads->ntiles, N, A, heads->ba, heads->bc, const_cast<float*>(probs), heads->values_out};
   const int samplers = mw.W > 0 ? mw.W : 1;
   int nshift = N * PRE_BANDS;                       // large path: one round of the 256 CUs (one workgroup per CU there)
   if (nshift > 256 - samplers) nshift = 256 - samplers > 32 ? 256 - samplers : 32;
-  if (large)
+  if (large && hs.partial)
+    launch_k((synth_step_a_mt_kernel<2, true>), dim3(samplers + nshift), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
+             mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
+             (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
+             (uint32_t*)raw_scratch, reinterpret_cast<const MtAhead*>(mt_ahead), hs);
+  else if (large)
     launch_k(synth_step_a_mt_kernel<2>, dim3(samplers + nshift), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A,
              mt_state, actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
-             (uint32_t*)raw_scratch, reinterpret_cast<const MtAhead*>(mt_ahead));
+             (uint32_t*)raw_scratch, reinterpret_cast<const MtAhead*>(mt_ahead), hs);
   else
     launch_k(synth_step_a_mt_kernel<1>, dim3(1 + N * PRE_BANDS), dim3(256), (hipStream_t)stream, PROF_WHOLE, probs, A, mt_state,
              actions, seed, env_offset, N, terminal_threshold, step_base_dev, step_offset, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards_out, masks_out, ep_reward, ep_len, (FinishedRing*)finished, mw,
-             (uint32_t*)raw_scratch, (const MtAhead*)nullptr);
+             (uint32_t*)raw_scratch, (const MtAhead*)nullptr, hs);
   }
   if (raw_scratch) launch_preprocess_after_step(raw_scratch, N, stack_in, stack_out, stack_out2, masks_out, (hipStream_t)stream);
   PAAC_CHECK_HIP(hipGetLastError());

@@ -263,6 +263,7 @@ def test_synthetic_env_matches_host_spec(raw_frames):
                                       # spare workgroup of the fc launch, csrc/mt_ahead.h): configs[4] and configs[2] per GPU
                                       ("NATURE", 18, 128), ("NATURE", 4, 256), ("NATURE", 9, 100)])
 def test_act_step_equals_separate_calls(arch, A, N, managed):
+    from paac_amd._lib import check as _lib_check
     """paac_act_step_mt (forward with the head contractions in the fc epilogue, then heads finish + MT19937 sampler +
     synthetic env step in ONE launch) == paac_forward + paac_sample_mt + paac_synth_step, bit for bit, over consecutive
     steps (probabilities, values, actions, stream position, stacks, rewards, masks, episode bookkeeping)."""
@@ -304,8 +305,17 @@ def test_act_step_equals_separate_calls(arch, A, N, managed):
             # workgroup builds its own blocks and doubles there)
             for d in (a, b):
                 hip_ops.sample_mt(d["probs"], d["mt"], scratch, d["act"])
+        if walk is not None and managed and step in (2, 6):
+            # the sampler workgroups finish the heads of their own environments there and report exact zeros with their
+            # tickets: make one report a zero it has not seen -- the last-ticket workgroup then finishes ALL heads and walks
+            # the serial way; ordinary probabilities, so the result is unchanged
+            _lib_check(ctx.lib.paac_debug_report_zero(0 if step == 2 else 3))
         ctx.act_step_mt(p, a["s0"], a["mt"], a["act"], a["probs"], a["val"], env_seed, off, thr, a["tick"], 0, a["s1"],
                         a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"], walk_scratch=walk)
+        if walk is not None and managed and step in (2, 6):
+            torch.cuda.synchronize()
+            _lib_check(ctx.lib.paac_debug_report_zero(-1))
+            assert int(walk[:4].view(torch.int32).item()) == 0        # the ticket word is back at 0
         ctx.forward(p, b["s0"], probs=b["probs"], values=b["val"])
         hip_ops.sample_mt(b["probs"], b["mt"], scratch, b["act"])
         hip_ops.synth_step(env_seed, off, b["act"], thr, b["tick"], 0, b["s0"], b["s1"], b["rew"], b["msk"], b["ep_r"],
