@@ -323,6 +323,8 @@ int paac_debug_get_tuning(paac_ctx* ctx, int op, int batch_class, int* cfg, int*
 /* The user architecture compiled into this library: returns 1 and fills nconv (2 or 3), filters3[3] (0 for an absent third
  * layer) and fc_width; returns 0 (and zeros) for the stock library. */
 int paac_user_arch(int32_t* nconv, int32_t* filters3, int32_t* fc_width);
+/* ... and its layers' kernel sizes and strides (VALID convolutions, networks.py:12-21; 0 for an absent layer). */
+int paac_user_arch_layers(int32_t* sizes3, int32_t* strides3);
 
 /* Diagnostic: writes {s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks} to out2_dev[0..1]. */
 int paac_debug_clock(uint64_t* out2_dev, paac_stream_t stream);

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "paac_prof_read_mix": (c_int, [c_void_p, POINTER(c_int32), c_int]),
     "paac_prof_name": (c_char_p, [c_int]),
     "paac_user_arch": (c_int, [POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "paac_user_arch_layers": (c_int, [POINTER(c_int32), POINTER(c_int32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -126,8 +127,9 @@ def user_arch():
     nconv, filters, fc = c_int32(), (c_int32 * 3)(), c_int32()
     if not load().paac_user_arch(ctypes.byref(nconv), filters, ctypes.byref(fc)):
         return None
-    sizes = [(8, 4), (4, 2), (3, 1)]
-    return [(int(filters[i]),) + sizes[i] for i in range(nconv.value)], int(fc.value)
+    sizes, strides = (c_int32 * 3)(), (c_int32 * 3)()
+    load().paac_user_arch_layers(sizes, strides)
+    return [(int(filters[i]), int(sizes[i]), int(strides[i])) for i in range(nconv.value)], int(fc.value)
 
 
 def load():

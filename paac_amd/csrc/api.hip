@@ -31,11 +31,22 @@ ArchSpec arch_spec(int arch) {
     s.fc = 512;
 #ifdef PAAC_USER_ARCH
   } else if (arch == PAAC_ARCH_USER) {
+    // layer shapes from the build's -DPAAC_USER_* flags, like UserNet (net_common.h): VALID convolutions over 84 x 84 x 4
+#ifndef PAAC_USER_K1
+#define PAAC_USER_K1 8
+#define PAAC_USER_S1 4
+#define PAAC_USER_K2 4
+#define PAAC_USER_S2 2
+#define PAAC_USER_K3 3
+#define PAAC_USER_S3 1
+#endif
+    constexpr int o1 = (84 - PAAC_USER_K1) / PAAC_USER_S1 + 1, o2 = (o1 - PAAC_USER_K2) / PAAC_USER_S2 + 1;
+    constexpr int o3 = PAAC_USER_NCONV == 3 ? (o2 - PAAC_USER_K3) / PAAC_USER_S3 + 1 : o2;
     s.nconv = PAAC_USER_NCONV;
-    s.conv[0] = ConvSpec{84, 84, 4, 20, 20, PAAC_USER_C1, 8, 4};
-    s.conv[1] = ConvSpec{20, 20, PAAC_USER_C1, 9, 9, PAAC_USER_C2, 4, 2};
-    if (PAAC_USER_NCONV == 3) s.conv[2] = ConvSpec{9, 9, PAAC_USER_C2, 7, 7, PAAC_USER_C3, 3, 1};
-    s.flat = PAAC_USER_NCONV == 3 ? 49 * PAAC_USER_C3 : 81 * PAAC_USER_C2;
+    s.conv[0] = ConvSpec{84, 84, 4, o1, o1, PAAC_USER_C1, PAAC_USER_K1, PAAC_USER_S1};
+    s.conv[1] = ConvSpec{o1, o1, PAAC_USER_C1, o2, o2, PAAC_USER_C2, PAAC_USER_K2, PAAC_USER_S2};
+    if (PAAC_USER_NCONV == 3) s.conv[2] = ConvSpec{o2, o2, PAAC_USER_C2, o3, o3, PAAC_USER_C3, PAAC_USER_K3, PAAC_USER_S3};
+    s.flat = PAAC_USER_NCONV == 3 ? o3 * o3 * PAAC_USER_C3 : o2 * o2 * PAAC_USER_C2;
     s.fc = PAAC_USER_H;
 #endif
   } else {
@@ -604,6 +615,23 @@ int paac_user_arch(int32_t* nconv, int32_t* filters3, int32_t* fc_width) {
   if (nconv) *nconv = 0;
   if (fc_width) *fc_width = 0;
   if (filters3) filters3[0] = filters3[1] = filters3[2] = 0;
+  return 0;
+#endif
+}
+
+int paac_user_arch_layers(int32_t* sizes3, int32_t* strides3) {
+#ifdef PAAC_USER_ARCH
+  const ArchSpec s = arch_spec(PAAC_ARCH_USER);
+  for (int i = 0; i < 3; ++i) {
+    if (sizes3) sizes3[i] = i < s.nconv ? s.conv[i].k : 0;
+    if (strides3) strides3[i] = i < s.nconv ? s.conv[i].stride : 0;
+  }
+  return 1;
+#else
+  for (int i = 0; i < 3; ++i) {
+    if (sizes3) sizes3[i] = 0;
+    if (strides3) strides3[i] = 0;
+  }
   return 0;
 #endif
 }

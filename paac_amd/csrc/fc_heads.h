@@ -20,6 +20,15 @@
 
 namespace paac {
 
+// waves per workgroup of fc_heads_kernel for an fc layer of `flat` inputs: they split the flat / 16 K groups evenly and each
+// needs more than the prefetch depth (8) of them; 0 = no such split (the layer then runs on the split-K GEMM at every batch)
+constexpr int fc_heads_waves(const int flat) {
+  const int g = flat / 16;
+  for (const int w : {7, 9, 8, 6, 5, 10, 4, 12, 3})
+    if (flat % 16 == 0 && g % w == 0 && g / w > 8) return w;
+  return 0;
+}
+
 constexpr int kFcHeadsMaxRows = 64;      // one finishing workgroup (it can be workgroup 0 of the sampler + env-step launch)
 constexpr int kFcHeadsMidRows = 256;     // acting batches up to here take the same fc kernel, finished by heads_finish_rows_kernel
 

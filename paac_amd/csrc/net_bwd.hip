@@ -156,6 +156,54 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinalizeArgs a
   if (live && r == 0) *reinterpret_cast<f32x4*>(sg.dst + i) = v;
 }
 
+// Data gradient of ONE VALID convolution of any kernel size / stride (a user architecture outside the reference trunks' layer
+// shapes, networks.py:117-120): dX[b, iy, ix, c] = relu'(X) * sum over the outputs (oy, ox) the pixel fed -- iy = oy S + ky,
+// ix = ox S + kx -- and their channels of dY[b, oy, ox, co] * W[ky, kx, c, co].  Plain fp32 FMAs in a fixed order, one thread
+// per (pixel, input channel), 16-byte loads along the output channels: the correctness path for arbitrary geometry, not a
+// tuned one (the family's layers keep their MFMA forms and the fused data-gradient tower).
+template <class G, int COUT>
+__global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float* __restrict__ dY, const float* __restrict__ Wt,
+                                                                const float* __restrict__ X, float* __restrict__ dX,
+                                                                const int batch) {
+  static_assert(COUT % 4 == 0, "output channels are read four at a time");
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)batch * G::IH * G::IW * G::C;
+  if (gid >= total) return;
+  const int c = (int)(gid % G::C);
+  long pix = gid / G::C;
+  const int ix = (int)(pix % G::IW);
+  pix /= G::IW;
+  const int iy = (int)(pix % G::IH);
+  const int b = (int)(pix / G::IH);
+  float acc = 0.f;
+  if (X[gid] > 0.f) {
+    for (int ky = iy % G::S; ky < G::KH && ky <= iy; ky += G::S) {
+      const int oy = (iy - ky) / G::S;
+      if (oy >= G::OH) continue;
+      for (int kx = ix % G::S; kx < G::KW && kx <= ix; kx += G::S) {
+        const int ox = (ix - kx) / G::S;
+        if (ox >= G::OW) continue;
+        const f32x4* dy = reinterpret_cast<const f32x4*>(dY + ((size_t)(b * G::OH + oy) * G::OW + ox) * COUT);
+        const f32x4* w = reinterpret_cast<const f32x4*>(Wt + ((size_t)(ky * G::KW + kx) * G::C + c) * COUT);
+#pragma unroll 4
+        for (int q = 0; q < COUT / 4; ++q) {
+          const f32x4 a = dy[q], v = w[q];
+          acc = fmaf(a[0], v[0], acc);
+          acc = fmaf(a[1], v[1], acc);
+          acc = fmaf(a[2], v[2], acc);
+          acc = fmaf(a[3], v[3], acc);
+        }
+      }
+    }
+  }
+  dX[gid] = acc;
+}
+template <class G, int COUT>
+static void launch_dgrad_direct(const float* dY, const float* Wt, const float* X, float* dX, int batch, hipStream_t s) {
+  const long total = (long)batch * G::IH * G::IW * G::C;
+  launch_k(conv_dgrad_direct_kernel<G, COUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), s, PROF_WHOLE, dY, Wt, X, dX, batch);
+}
+
 int launch_pack_dgrad(paac_ctx* ctx, const float* params, hipStream_t s) {
   if (!ctx->tower_on) return 0;
   const paac_layout& L = ctx->layout;
@@ -308,9 +356,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   if constexpr (NT::NCONV == 3) {
     // (4) conv3 wgrad: dW3[576,64] = patches(a2)^T dY3;  (5) conv3 dgrad -> dact[1] masked by relu'(a2)
     const int feats = NT::G3::FEATS;
-    GemmArgs gw = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, slab, nullptr, feats, NT::C3, batch * 49, NT::C3, NT::C3);
+    constexpr int P2 = NT::G2::OPIX, P3 = NT::G3::OPIX;
+    GemmArgs gw = make_args(W.act[1], (size_t)batch * P2 * NT::C2 * 4, ctx->dact[2], (size_t)batch * P3 * NT::C3 * 4, slab, nullptr, feats, NT::C3, batch * P3, NT::C3, NT::C3);
     gw.slab_rows = feats + 1;
-    GemmArgs gd = make_args(ctx->dact[2], (size_t)batch * 49 * NT::C3 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, ctx->dact[1], W.act[1], batch * 81, NT::C2, 9 * NT::C3, 0, NT::C2);
+    GemmArgs gd = make_args(ctx->dact[2], (size_t)batch * P3 * NT::C3 * 4, w3, (size_t)feats * NT::C3 * 4, ctx->dact[1], W.act[1], batch * P2, NT::C2, 9 * NT::C3, 0, NT::C2);
     // tap (kh, kw) of the full correlation reads the forward tap (2 - kh, 2 - kw)
     gd.tap_base[0] = 8 * NT::C2 * NT::C3;
     gd.tap_sh = -3 * NT::C2 * NT::C3;
@@ -368,9 +417,12 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
         hg.blocks = NT::H / 32 + 1;
       }
       launch_k(dgrad_tower_kernel, dim3((unsigned)(batch + hg.blocks)), dim3(512), s, PROF_WHOLE, da, hg);
-    } else {
+    } else if constexpr (NT::FAMILY) {
       ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
       launch_dgrad<typename NT::G3D, NT::C2, NT::C3, EPI_MASK>(gd, 1, ctx->tune[OP_CONV3_DGRAD][cls], s);
+    } else {
+      ProfScope ps(ctx, F_CONV3_DGRAD, batch, s);
+      launch_dgrad_direct<typename NT::G3, NT::C3>(ctx->dact[2], w3, W.act[1], ctx->dact[1], batch, s);
     }
     wgrad_out(i_w3, feats, NT::C3, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C3;
@@ -378,9 +430,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   // (6) conv2 wgrad;  (7) conv2 dgrad by output parity (4 classes in blockIdx.z) -> dact[0] masked by relu'(a1)
   {
     const int feats = NT::G2::FEATS;
-    GemmArgs gw = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, slab, nullptr, feats, NT::C2, batch * 81, NT::C2, NT::C2);
+    constexpr int P1 = NT::G1::OPIX, P2 = NT::G2::OPIX;
+    GemmArgs gw = make_args(W.act[0], (size_t)batch * P1 * NT::C1 * 4, ctx->dact[1], (size_t)batch * P2 * NT::C2 * 4, slab, nullptr, feats, NT::C2, batch * P2, NT::C2, NT::C2);
     gw.slab_rows = feats + 1;
-    GemmArgs gd = make_args(ctx->dact[1], (size_t)batch * 81 * NT::C2 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
+    GemmArgs gd = make_args(ctx->dact[1], (size_t)batch * P2 * NT::C2 * 4, w2, (size_t)feats * NT::C2 * 4, ctx->dact[0], W.act[0], batch * 100, NT::C1, 4 * NT::C2, 0, NT::C1);
     // output parity (py, px), tap (kh, kw) of the 2x2 dense correlation reads forward tap
     // (py + 2 (1 - kh), px + 2 (1 - kw)) of the 4x4 kernel
     for (int par = 0; par < 4; ++par) gd.tap_base[par] = (((par >> 1) + 2) * 4 + (par & 1) + 2) * NT::C1 * NT::C2;
@@ -392,9 +445,9 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     // launch.  conv1 runs its 4-wave configuration here (alone its 8-wave one is faster; in the pair it is not).
     if constexpr (NT::NCONV == 3) {
       static const bool pair_on = env_int("PAAC_WGRAD_PAIR", 1) != 0;
-      const int f1 = 256;
-      GemmArgs g1 = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * 400 * NT::C1 * 4,
-                              slab + (long)W_SPLITS_MAX * (feats + 1) * NT::C2, nullptr, f1, NT::C1, batch * 400, NT::C1, NT::C1);
+      const int f1 = NT::G1::FEATS;
+      GemmArgs g1 = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * P1 * NT::C1 * 4,
+                              slab + (long)W_SPLITS_MAX * (feats + 1) * NT::C2, nullptr, f1, NT::C1, batch * P1, NT::C1, NT::C1);
       g1.slab_rows = f1 + 1;
       int c2, k2, x2, c1, k1, x1;
       resolve_wgrad<false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], c2, k2, x2);
@@ -420,7 +473,10 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
       splits = launch_wgrad<typename NT::G2, false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], s);
     }
-    if (!(NT::NCONV == 3 && ctx->tower_on)) {     // Nature with the tower: done by dgrad_tower_kernel above
+    if constexpr (!NT::FAMILY) {
+      ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
+      launch_dgrad_direct<typename NT::G2, NT::C2>(ctx->dact[1], w2, W.act[0], ctx->dact[0], batch, s);
+    } else if (!(NT::NCONV == 3 && ctx->tower_on)) {     // Nature with the tower: done by dgrad_tower_kernel above
       ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
       launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(gd, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
     }
@@ -429,11 +485,12 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
   }
   // (8) conv1 wgrad from the u8 frames
   {
-    const int feats = 256;
+    const int feats = NT::G1::FEATS;
+    constexpr int P1 = NT::G1::OPIX;
     int splits = conv1_splits_done;
     if (splits == 0) {
       ProfScope ps(ctx, F_CONV1_WGRAD, batch, s);
-      GemmArgs g = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * 400 * NT::C1 * 4, slab, nullptr, feats, NT::C1, batch * 400, NT::C1, NT::C1);
+      GemmArgs g = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * P1 * NT::C1 * 4, slab, nullptr, feats, NT::C1, batch * P1, NT::C1, NT::C1);
       g.slab_rows = feats + 1;
       splits = launch_wgrad<typename NT::G1, true, NT::C1>(g, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], s);
     }
@@ -474,8 +531,8 @@ int64_t wslab_floats_needed(int arch) {
                                     257 * NatureNet::C1);
   if (OtherNet::NCONV == 3)
     return (int64_t)W_SPLITS_MAX * ((OtherNet::G3::FEATS + 1) * OtherNet::C3 + (OtherNet::G2::FEATS + 1) * OtherNet::C2 +
-                                    257 * OtherNet::C1);
-  return (int64_t)W_SPLITS_MAX * ((OtherNet::G2::FEATS + 1) * OtherNet::C2 + 257 * OtherNet::C1);
+                                    (OtherNet::G1::FEATS + 1) * OtherNet::C1);
+  return (int64_t)W_SPLITS_MAX * ((OtherNet::G2::FEATS + 1) * OtherNet::C2 + (OtherNet::G1::FEATS + 1) * OtherNet::C1);
 }
 
 }  // namespace paac

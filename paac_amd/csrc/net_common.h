@@ -12,6 +12,8 @@ namespace paac {
 // Compile-time network descriptions.
 struct NatureNet {
   static constexpr int NCONV = 3, C1 = 32, C2 = 64, C3 = 64, H = 512, FLAT = 3136;
+  static constexpr bool FAMILY = true;      // conv 8x8 / 4 -> conv 4x4 / 2 [-> conv 3x3 / 1]: the shapes the fused kernels and
+                                            // the MFMA data-gradient forms are written for
   using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
   using G2 = Geom<20, 20, 32, 9, 9, 2, 0, 0, 4, 4>;
   using G3 = Geom<9, 9, 64, 7, 7, 1, 0, 0, 3, 3>;
@@ -22,6 +24,7 @@ struct NatureNet {
 };
 struct NipsNet {
   static constexpr int NCONV = 2, C1 = 16, C2 = 32, C3 = 32, H = 256, FLAT = 2592;
+  static constexpr bool FAMILY = true;
   using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
   using G2 = Geom<20, 20, 16, 9, 9, 2, 0, 0, 4, 4>;
   using G3 = Geom<9, 9, 32, 7, 7, 1, 0, 0, 3, 3>;      // unused
@@ -36,18 +39,37 @@ struct NipsNet {
 // (paac_amd/build.py: build_user_arch; -DPAAC_USER_ARCH -DPAAC_USER_NCONV=.. -DPAAC_USER_C1=.. ...).  It takes the place
 // of the NIPS geometry in the two-way dispatch: such a library serves PAAC_ARCH_NATURE and PAAC_ARCH_USER.
 #ifdef PAAC_USER_ARCH
+// per-layer kernel size / stride: the family's unless the build says otherwise (paac_amd/build.py: build_user_arch)
+#ifndef PAAC_USER_K1
+#define PAAC_USER_K1 8
+#define PAAC_USER_S1 4
+#define PAAC_USER_K2 4
+#define PAAC_USER_S2 2
+#define PAAC_USER_K3 3
+#define PAAC_USER_S3 1
+#endif
 struct UserNet {
   static constexpr int NCONV = PAAC_USER_NCONV, C1 = PAAC_USER_C1, C2 = PAAC_USER_C2;
   static constexpr int C3 = (PAAC_USER_NCONV == 3) ? PAAC_USER_C3 : PAAC_USER_C2, H = PAAC_USER_H;
-  static constexpr int FLAT = (PAAC_USER_NCONV == 3) ? 49 * C3 : 81 * C2;
+  static constexpr int K1 = PAAC_USER_K1, S1 = PAAC_USER_S1, K2 = PAAC_USER_K2, S2 = PAAC_USER_S2;
+  static constexpr int K3 = (PAAC_USER_NCONV == 3) ? PAAC_USER_K3 : 1, S3 = (PAAC_USER_NCONV == 3) ? PAAC_USER_S3 : 1;
+  // VALID convolutions over the 84 x 84 x 4 input (networks.py:12-21)
+  static constexpr int O1 = (84 - K1) / S1 + 1, O2 = (O1 - K2) / S2 + 1, O3 = (PAAC_USER_NCONV == 3) ? (O2 - K3) / S3 + 1 : O2;
+  static constexpr int FLAT = (PAAC_USER_NCONV == 3) ? O3 * O3 * C3 : O2 * O2 * C2;
+  static constexpr bool FAMILY = K1 == 8 && S1 == 4 && K2 == 4 && S2 == 2 && (PAAC_USER_NCONV == 2 || (K3 == 3 && S3 == 1));
   static_assert(NCONV == 2 || NCONV == 3, "two or three conv layers");
   static_assert(C1 % 16 == 0 && C2 % 16 == 0 && C3 % 16 == 0 && C1 >= 16 && C2 >= 16 && C3 >= 16, "filter counts: multiples of 16");
   static_assert(H % 256 == 0 && H >= 256, "fc width: a multiple of 256");
-  using G1 = Geom<84, 84, 4, 20, 20, 4, 0, 0, 8, 8>;
-  using G2 = Geom<20, 20, C1, 9, 9, 2, 0, 0, 4, 4>;
-  using G3 = Geom<9, 9, C2, 7, 7, 1, 0, 0, 3, 3>;
+  static_assert((K1 * 4) % 16 == 0, "conv1: kernel width x 4 input channels must be a multiple of 16 (one MFMA K group never "
+                                    "straddles two kernel rows): sizes 4, 8, 12, 16");
+  static_assert(O1 >= 1 && O2 >= 1 && O3 >= 1 && K1 >= 1 && K2 >= 1 && K3 >= 1 && S1 >= 1 && S2 >= 1 && S3 >= 1, "layer shapes");
+  using G1 = Geom<84, 84, 4, O1, O1, S1, 0, 0, K1, K1>;
+  using G2 = Geom<O1, O1, C1, O2, O2, S2, 0, 0, K2, K2>;
+  using G3 = Geom<O2, O2, C2, O3, O3, S3, 0, 0, K3, K3>;
   using GFC = Geom<1, 1, FLAT, 1, 1, 1, 0, 0, 1, 1>;
   using GFCH = Geom<1, 1, H, 1, 1, 1, 0, 0, 1, 1>;
+  // the family's MFMA data-gradient geometries (conv3: full correlation; conv2: one output-parity class); other layer
+  // shapes take the direct data-gradient kernel (net_bwd.hip: conv_dgrad_direct_kernel)
   using G3D = Geom<7, 7, C3, 9, 9, 1, 2, 2, 3, 3>;
   using G2D = Geom<9, 9, C2, 10, 10, 1, 1, 1, 2, 2>;
 };

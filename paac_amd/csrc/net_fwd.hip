@@ -283,7 +283,8 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     ctx->keep_row = -1;
   }
   const bool keep_acts = wsi == 1 || !ctx->managed_weights;          // fp32 conv activations / h kept for backward and read-back
-  const bool small_tail = batch <= kFcHeadsMaxRows && !ph.enabled && !st.enabled;   // fc + head partials kernel (fc_heads.h)
+  constexpr int NW = fc_heads_waves(NT::FLAT);      // 0: this fc geometry has no fc + head partials kernel
+  const bool small_tail = NW > 0 && batch <= kFcHeadsMaxRows && !ph.enabled && !st.enabled;   // fc + head partials kernel (fc_heads.h)
   // conv3 -> fc hand-off in the fc kernel's fragment order: rows are padded to 16 inside the activation buffer (max_batch
   // is rounded up at allocation)
   // ... and acting batches of up to 256 rows (the 128- / 256-environment shards) take the same fc kernel, finished by a
@@ -317,12 +318,14 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   }
   if (!tower && !tower2) {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
-    GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)256 * NT::C1 * 4, W.act[0], b1, batch * 400, NT::C1, 256, NT::C1, NT::C1);
+    constexpr int P1 = NT::G1::OPIX, F1 = NT::G1::FEATS;
+    GemmArgs g = make_args(states, (size_t)batch * 28224, w1, (size_t)F1 * NT::C1 * 4, W.act[0], b1, batch * P1, NT::C1, F1, NT::C1, NT::C1);
     launch_fwd<typename NT::G1, true, NT::C1, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV1_FWD][cls], s);
   }
   if (!tower && !tower2) {
     ProfScope ps(ctx, F_CONV2_FWD, batch, s);
-    GemmArgs g = make_args(W.act[0], (size_t)batch * 400 * NT::C1 * 4, w2, (size_t)16 * NT::C1 * NT::C2 * 4, W.act[1], b2, batch * 81, NT::C2, 16 * NT::C1, NT::C2, NT::C2);
+    constexpr int P1 = NT::G1::OPIX, P2 = NT::G2::OPIX, F2 = NT::G2::FEATS;
+    GemmArgs g = make_args(W.act[0], (size_t)batch * P1 * NT::C1 * 4, w2, (size_t)F2 * NT::C2 * 4, W.act[1], b2, batch * P2, NT::C2, F2, NT::C2, NT::C2);
     launch_fwd<typename NT::G2, false, NT::C2, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV2_FWD][cls], s);
   }
   const float* last = W.act[1];
@@ -331,13 +334,14 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   }
   if constexpr (NT::NCONV == 3) if (!tower) {
     ProfScope ps(ctx, F_CONV3_FWD, batch, s);
-    GemmArgs g = make_args(W.act[1], (size_t)batch * 81 * NT::C2 * 4, w3, (size_t)9 * NT::C2 * NT::C3 * 4, W.act[2], b3, batch * 49, NT::C3, 9 * NT::C2, NT::C3, NT::C3);
+    constexpr int P2 = NT::G2::OPIX, P3 = NT::G3::OPIX, F3 = NT::G3::FEATS;
+    GemmArgs g = make_args(W.act[1], (size_t)batch * P2 * NT::C2 * 4, w3, (size_t)F3 * NT::C3 * 4, W.act[2], b3, batch * P3, NT::C3, F3, NT::C3, NT::C3);
     launch_fwd<typename NT::G3, false, NT::C3, EPI_BIAS_RELU>(g, ctx->tune[OP_CONV3_FWD][cls], s);
     last = W.act[2];
   }
   // Small acting / evaluation batches: fc with the head contractions folded into its epilogue (fc_heads.h), then the
   // head finish -- as its own one-workgroup launch here, or (defer_heads) inside the caller's sampler launch.
-  if (small_tail || mid_tail) {
+  if constexpr (NW > 0) if (small_tail || mid_tail) {
     if (wsi == 1) ctx->heads_pending_rows = 0;
     constexpr int NTILES = NT::H / 16;
     float* partial = W.fc_slab;      // [NTILES][batch][A + 1]: fits the split-K slab buffer
@@ -347,7 +351,6 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     {
       ProfScope ps(ctx, F_FC_FWD, batch, s);
       prof_mix(1);     // fp32 MFMA
-      constexpr int NW = (NT::FLAT / 16) % 7 == 0 ? 7 : 9;      // waves per workgroup: divides the K groups evenly
       // one-shot (paac_act_step_mt): a spare workgroup makes the next sampling step's MT19937 doubles meanwhile (mt_ahead.h)
       MtAheadArgs ah{ctx->ahead_state, ctx->ahead_state ? reinterpret_cast<MtAhead*>(ctx->mt_ahead) : nullptr, ctx->ahead_D};
       ctx->ahead_state = nullptr;

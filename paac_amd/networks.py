@@ -10,8 +10,10 @@ New architectures: the reference lets users subclass Network and set `self.outpu
 README.md:80-83).  Here an architecture is a compiled kernel chain -- its geometry is a template argument of every kernel
 -- so `define_architecture(name, convs, fc)` compiles a library for it on first use (paac_amd/build.py:
 build_user_arch, about a minute of hipcc, cached in-tree) and returns the trunk class to mix into PolicyVNetwork, exactly
-like NIPSNetwork / NatureNetwork.  Supported: the reference trunks' layer shapes (conv 8x8 / 4, conv 4x4 / 2[, conv 3x3 /
-1], fc) with any filter counts that are multiples of 16 and an fc width that is a multiple of 256.
+like NIPSNetwork / NatureNetwork.  Supported: two or three VALID conv layers of any kernel size and stride (the first
+layer's size 4, 8, 12 or 16) with filter counts that are multiples of 16, and an fc width that is a multiple of 256.  The
+reference trunks' layer shapes (conv 8x8 / 4, conv 4x4 / 2[, conv 3x3 / 1]) run on the MFMA data-gradient forms; other
+shapes take the generic contraction for forward / weight gradient and a direct kernel for the data gradient.
 """
 import glob
 import logging

@@ -66,8 +66,9 @@ BUILD_FLAGS = (
     (("--device_preprocess",), "device_preprocess", False, bool_arg,
      "host environments hand out raw screen pairs; max + resize + frame history run on the GPU"),
     (("--user_arch",), "user_arch", "", None,
-     "a user architecture instead of --arch: filter counts of the 2 or 3 conv layers (8x8/4, 4x4/2[, 3x3/1]) and the fc "
-     "width, e.g. 32,64,64,1024 (compiled on first use)"),
+     "a user architecture instead of --arch (compiled on first use): filter counts of the 2 or 3 conv layers of the "
+     "reference trunks' shapes (8x8/4, 4x4/2[, 3x3/1]) and the fc width, e.g. 32,64,64,1024 -- or filters:size:stride per "
+     "layer, e.g. 32:8:4,64:5:2,64:3:1,512"),
     (("--checkpoint_format",), "checkpoint_format", "npz", None,
      "container of the checkpoints written: 'npz', or 'tf' = the reference's TensorFlow V2 tensor bundle "
      "(.index + .data-00000-of-00001); both are read"),
@@ -101,9 +102,8 @@ def get_network_and_environment_creator(args, random_seed=3):
         # networks.py:117-120 / README.md:80-83: a new trunk mixed into PolicyVNetwork
         from .networks import define_architecture
         from .policy_v_network import PolicyVNetwork
-        widths = [int(v) for v in str(args.user_arch).split(",")]
-        shapes = [(8, 4), (4, 2), (3, 1)]
-        trunk = define_architecture("USER", [(f,) + shapes[i] for i, f in enumerate(widths[:-1])], widths[-1])
+        from .build import parse_user_arch
+        trunk = define_architecture("USER", *parse_user_arch(args.user_arch))
         network_class = type("UserPolicyVNetwork", (PolicyVNetwork, trunk), {})
 
     def network_creator(name='local_learning'):

@@ -1,8 +1,8 @@
 """-m gpu: a user-defined architecture through the plugin surface (reference networks.py:117-120, README.md:80-83: "subclass
 the trunk and mix it into PolicyVNetwork").  Here an architecture is a compiled geometry: networks.define_architecture
 builds a library for it (paac_amd/build.py: build_user_arch) and a process holds one such library, so the checks run in a
-child process.  Parity: a third architecture -- three conv layers of 16 / 32 / 32 filters, fc 256 -- against the oracle with
-its ARCHS entry; "parity unpinned" at the TensorFlow boundary like the stock trunks (oracle/network.py header)."""
+child process.  Parity: a third architecture -- three conv layers of 16 / 32 / 32 filters, fc 256 -- and a fourth with a layer
+shape the reference trunks do not have (conv 5x5 / 2) against the oracle with their ARCHS entries; "parity unpinned" at the TensorFlow boundary like the stock trunks (oracle/network.py header)."""
 import os
 import subprocess
 import sys
@@ -21,7 +21,7 @@ from oracle import network as onet
 from paac_amd import _lib, hip_ops, networks
 from paac_amd.policy_v_network import PolicyVNetwork
 
-CONVS, FC, A, B = [(16, 8, 4), (32, 4, 2), (32, 3, 1)], 256, 6, 40
+CONVS, FC, A, B = %(convs)r, %(fc)d, 6, 40
 onet.ARCHS["TINY3"] = (CONVS, FC)
 Trunk = networks.define_architecture("TINY3", CONVS, FC)          # builds / finds the library, makes it this process's
 assert _lib.user_arch() == (CONVS, FC)
@@ -39,7 +39,8 @@ ctx = hip_ops.Context(_lib.ARCH_USER, A, max_batch=B)
 names = [t["name"] for t in ctx.layout["tensors"]]
 assert names[:8] == ["conv1_weights", "conv1_biases", "conv2_weights", "conv2_biases", "conv3_weights", "conv3_biases",
                      "fc4_weights", "fc4_biases"]
-assert [t["shape"] for t in ctx.layout["tensors"]][6] == (49 * 32, 256)
+assert [t["shape"] for t in ctx.layout["tensors"]][6] == (onet.layer_dims("TINY3")[1], FC)
+assert [t["shape"] for t in ctx.layout["tensors"]][2] == (CONVS[1][1], CONVS[1][1], CONVS[0][0], CONVS[1][0])
 flat = np.zeros(ctx.layout["total"], dtype=np.float32)
 for t in ctx.layout["tensors"]:
     flat[t["offset"]:t["offset"] + t["size"]] = params[t["name"]].reshape(-1)
@@ -74,7 +75,7 @@ except _lib.PaacHipError as exc:
 # -- the whole learner on it: device loop, checkpoint under the reference's naming, resume ----------------------------
 from paac_amd import train
 from paac_amd.paac import PAACLearner
-args = train.get_arg_parser().parse_args(["-g", "qbert", "--user_arch", "16,32,32,256", "-ec", "8", "-ew", "0",
+args = train.get_arg_parser().parse_args(["-g", "qbert", "--user_arch", %(flag)r, "-ec", "8", "-ew", "0",
                                           "--max_global_steps", str(8 * 5 * 4), "-df", tempfile.mkdtemp(prefix="paac_user_")])
 nc, ec = train.get_network_and_environment_creator(args)
 learner = PAACLearner(nc, ec, args)
@@ -90,7 +91,13 @@ print("USER_ARCH_OK")
 """
 
 
-def test_user_architecture_runs_and_matches_the_oracle():
-    res = subprocess.run([sys.executable, "-c", _SCRIPT % dict(root=ROOT)], cwd=ROOT, capture_output=True, text=True,
-                         timeout=900)
+@pytest.mark.parametrize("convs,fc,flag", [
+    ([(16, 8, 4), (32, 4, 2), (32, 3, 1)], 256, "16,32,32,256"),                # the reference trunks' layer shapes, other widths
+    # a layer the reference trunks do not have -- 5x5 / 2 -- and with it other spatial sizes all the way down (20 -> 8 -> 6):
+    # forward and weight gradients on the generic MFMA contraction, data gradients on the direct kernel
+    ([(32, 8, 4), (64, 5, 2), (64, 3, 1)], 512, "32:8:4,64:5:2,64:3:1,512"),
+])
+def test_user_architecture_runs_and_matches_the_oracle(convs, fc, flag):
+    res = subprocess.run([sys.executable, "-c", _SCRIPT % dict(root=ROOT, convs=convs, fc=fc, flag=flag)], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "USER_ARCH_OK" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
