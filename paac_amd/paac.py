@@ -69,8 +69,8 @@ class DeviceRollout(object):
         self.graph_a = [None, None]
         self.graph_conv = [None, None]
         self.graph_b = None
-        self.graph_multi = None                        # MULTI consecutive cycles (parity 0 first) in one launch
-        self.graph_multi_long = None                   # MULTI_LONG of them
+        self.graph_multi = [None, None]                # MULTI consecutive cycles in one launch, by the ring parity they start at
+        self.graph_multi_long = [None, None]           # MULTI_LONG of them
         self.graph_ua = [None, None]                   # data parallel: update of the previous cycle + graph_a
         self.pending_update = False
         # data parallel: the cycle contains the gradient exchange
@@ -92,6 +92,8 @@ class DeviceRollout(object):
         # the replayed collective against the eager one
         self.exchange_mode = "none" if not self.phased else ("split" if not self.single_exchange else "single")
         self.exchange_fallback = None
+        self.short_first = os.environ.get("PAAC_SHORT_GRAPH_FIRST", "1") != "0"
+        self.spin_sync = os.environ.get("PAAC_SPIN_SYNC", "1") != "0"
         self.verify_exchange = os.environ.get("PAAC_VERIFY_EXCHANGE", "1") != "0"
         # flat gradient = [conv tensors | fc_w fc_b actor critic]; the tail is 95 % of the bytes
         self.tail_offset = [t["offset"] for t in L.network.layout["tensors"] if t["name"].startswith("fc")][0]
@@ -231,9 +233,10 @@ class DeviceRollout(object):
                 with torch.cuda.stream(self.stream):
                     for parity in (0, 1):
                         self.graph_a[parity] = captured(lambda: cycle(parity, True))
-                    self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
-                    if self.MULTI_LONG > self.MULTI:
-                        self.graph_multi_long = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI_LONG)])
+                    for p0 in (0, 1):
+                        self.graph_multi[p0] = captured(lambda: [cycle((k + p0) & 1, True) for k in range(self.MULTI)])
+                        if self.MULTI_LONG > self.MULTI:
+                            self.graph_multi_long[p0] = captured(lambda: [cycle((k + p0) & 1, True) for k in range(self.MULTI_LONG)])
             except Exception as exc:      # noqa: BLE001 -- whatever the runtime / RCCL raised: keep training, eagerly
                 reason = "the capture raised: %s" % (exc,)
             # every rank takes the same route: one that kept replaying graphs beside a peer issuing its collectives eagerly
@@ -266,9 +269,10 @@ class DeviceRollout(object):
             if self.phased:
                 self.graph_b = captured(self._update)
             else:
-                self.graph_multi = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI)])
-                if self.MULTI_LONG > self.MULTI:
-                    self.graph_multi_long = captured(lambda: [cycle(k & 1, True) for k in range(self.MULTI_LONG)])
+                for p0 in (0, 1):
+                    self.graph_multi[p0] = captured(lambda: [cycle((k + p0) & 1, True) for k in range(self.MULTI)])
+                    if self.MULTI_LONG > self.MULTI:
+                        self.graph_multi_long[p0] = captured(lambda: [cycle((k + p0) & 1, True) for k in range(self.MULTI_LONG)])
 
     # -- trust, but verify: the captured exchange ---------------------------------------------------------
     def _cycle_state(self):
@@ -335,13 +339,18 @@ class DeviceRollout(object):
             with torch.cuda.stream(self.stream):
                 self.capture()            # first: a captured exchange that is refused changes which graphs exist
         while count > 0:
-            if self.use_graph and (not self.phased or self.graph_exchange) and self.parity == 0 and count >= self.MULTI:
+            if self.use_graph and (not self.phased or self.graph_exchange) and count >= self.MULTI:
+                # (an even number of cycles per launch: the ring parity is the same afterwards; there is a graph per starting
+                # parity -- a caller that has run an odd number of cycles, e.g. a 5-cycle warm-up, keeps the batched launches)
                 with torch.cuda.stream(self.stream):
-                    if self.graph_multi_long is not None and count >= self.MULTI_LONG:
-                        self.graph_multi_long.launch()
+                    # the SHORT graph first: submitting a replay costs host time in proportion to its nodes, and an idle GPU
+                    # waits for it -- behind MULTI cycles already running, the long graphs' submissions are hidden
+                    if self.graph_multi_long[self.parity] is not None and count >= self.MULTI_LONG and (
+                            self.short_first is False or count % self.MULTI_LONG < self.MULTI):
+                        self.graph_multi_long[self.parity].launch()
                         count -= self.MULTI_LONG
                         continue
-                    self.graph_multi.launch()
+                    self.graph_multi[self.parity].launch()
                 count -= self.MULTI
             else:
                 self.run_cycle()
@@ -389,6 +398,14 @@ class DeviceRollout(object):
             with torch.cuda.stream(self.stream):
                 self.graph_b.launch()
             self.pending_update = False
+        if self.spin_sync:
+            # poll instead of sleeping on the stream: the wake-up of a blocking synchronize costs tens of microseconds, which a
+            # caller that brackets short runs (bench.py's 20-cycle windows are 5 ms) pays every time
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            while not done.query():
+                pass
+            return
         self.stream.synchronize()
 
     def finished_episodes(self):
@@ -402,16 +419,16 @@ class DeviceRollout(object):
         return count, [(float(rewards[i]), int(lens[i])) for i in idx]
 
     def close(self):
-        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b, self.graph_multi,
-                  self.graph_multi_long,
+        for g in (self.graph_a[0], self.graph_a[1], self.graph_conv[0], self.graph_conv[1], self.graph_b, self.graph_multi[0],
+                  self.graph_multi[1], self.graph_multi_long[0], self.graph_multi_long[1],
                   self.graph_ua[0], self.graph_ua[1]):
             if g is not None:
                 g.close()
         self.graph_a = [None, None]
         self.graph_conv = [None, None]
         self.graph_b = None
-        self.graph_multi = None
-        self.graph_multi_long = None
+        self.graph_multi = [None, None]
+        self.graph_multi_long = [None, None]
         self.graph_ua = [None, None]
 
 

@@ -178,7 +178,7 @@ for mode in ("plain", "split", "single", "graph", "graph_refused"):
         assert ro.check_replicas("weights") and ro.check_replicas("grad")
     assert (ro.graph_ua[0] is not None) == (mode in ("split", "single", "graph_refused"))
     assert (ro.graph_conv[0] is not None) == (mode == "split")
-    assert (ro.graph_multi is not None) == (mode in ("plain", "graph"))      # MULTI cycles per launch survive the exchange
+    assert (ro.graph_multi[0] is not None) == (mode in ("plain", "graph"))      # MULTI cycles per launch survive the exchange
     ro.close()
 for mode in ("split", "single", "graph", "graph_refused"):
     assert np.array_equal(out[mode][0], out["plain"][0]), mode + ": weights differ from the unphased run"

@@ -285,8 +285,8 @@ def test_batched_graph_launches_equal_single_cycles():
         learner.global_step = learner.init_network()
         ro = DeviceRollout(learner, learner.environment_creator.device_env_spec, sampler="numpy", use_graph=True)
         if batched:
-            ro.run_cycles(1)            # parity 1: the next call must fall back to a single cycle first
-            ro.run_cycles(cycles - 1)   # 1 single + 2 x 4 batched + 1 single
+            ro.run_cycles(1)            # ring parity 1 from here: the batched graphs that START at parity 1
+            ro.run_cycles(cycles - 1)   # 2 x 4 batched + 2 single
         else:
             for _ in range(cycles):
                 ro.run_cycle()

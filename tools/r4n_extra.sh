@@ -1,0 +1,7 @@
+OUT=$1
+cd /tmp && export TMPDIR=/tmp
+B=$GRAFT_REPO_ROOT/bench.py
+for i in 1 2 3; do
+timeout -k 10 100 python3 $B --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/d_new_$i.json 2>> $OUT/err.txt; echo "new rc=$?"
+done
+timeout -k 10 100 python3 $B --gpus 1 --steps 20 --warmup 5 > $OUT/d_full.json 2>> $OUT/err.txt; echo "full rc=$?"
