@@ -201,6 +201,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   PAAC_CHECK_HIP(hipMalloc(&c->zeros, (size_t)(c->spec.fc > 1024 ? c->spec.fc : 1024) * sizeof(float)));
   PAAC_CHECK_HIP(hipMemset(c->zeros, 0, (size_t)(c->spec.fc > 1024 ? c->spec.fc : 1024) * sizeof(float)));
   c->keep_row = -1;
+  c->keep_h_only = 0;
   c->heads_pending_h = 0;
   PAAC_CHECK_HIP(hipMalloc(&c->mt_ahead, mt_ahead_bytes()));
   PAAC_CHECK_HIP(hipMemset(c->mt_ahead, 0, mt_ahead_bytes()));

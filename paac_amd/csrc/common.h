@@ -125,6 +125,7 @@ struct paac_ctx {
   // TRAINING activation set, so that an update over rows the acting steps have already computed needs no training forward
   // (weights are frozen inside a cycle).  -1 = off (one shot: the forward that honours it resets it).
   int keep_row;
+  int keep_h_only;                 // with keep_row: only the fc activations are kept (bootstrap rows: the update reads nothing else of them)
   int heads_pending_h;             // 1: the pending "slab" holds finished fc activations (bias + ReLU applied), one split
   float* zeros;                    // max(H) zero floats (the bias of heads that read finished activations)
   // csrc/mt_ahead.h: the record a spare workgroup of the acting forward's fc launch leaves for the sampling step behind it

@@ -278,9 +278,12 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   if constexpr (NT::NCONV == 2 && kTower2) tower2 = ctx->tower2_on != 0;
   // paac_keep_next_forward (one shot): this acting forward's rows are also kept in the training activation set
   int keep_row = -1;
+  bool keep_h_only = false;
   if (wsi == 0) {
     keep_row = ctx->keep_row;
+    keep_h_only = ctx->keep_h_only != 0;
     ctx->keep_row = -1;
+    ctx->keep_h_only = 0;
   }
   const bool keep_acts = wsi == 1 || !ctx->managed_weights;          // fp32 conv activations / h kept for backward and read-back
   constexpr int NW = fc_heads_waves(NT::FLAT);      // 0: this fc geometry has no fc + head partials kernel
@@ -308,13 +311,13 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
     prof_mix(3);       // conv1: u8 pixels x weights split into 3 bf16 terms
     prof_mix(6);       // conv2, conv3: six-product split-bf16
-    launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s, keepW, keep_row < 0 ? 0 : keep_row);
+    launch_tower(ctx, W, params, states, batch, keep_acts, packed3, s, keep_h_only ? nullptr : keepW, keep_row < 0 ? 0 : keep_row);
   }
   if (tower2) {
     ProfScope ps(ctx, F_CONV_TOWER, batch, s);
     prof_mix(3);       // conv1: u8 pixels x weights split into 3 bf16 terms
     prof_mix(6);       // conv2: six-product split-bf16
-    launch_tower2(ctx, W, params, states, batch, keep_acts, packed3, s, keepW, keep_row < 0 ? 0 : keep_row);
+    launch_tower2(ctx, W, params, states, batch, keep_acts, packed3, s, keep_h_only ? nullptr : keepW, keep_row < 0 ? 0 : keep_row);
   }
   if (!tower && !tower2) {
     ProfScope ps(ctx, F_CONV1_FWD, batch, s);
@@ -485,12 +488,14 @@ int launch_bootstrap_trunk(paac_ctx* ctx, const float* params, const uint8_t* st
   SynthStepArgs st;
   memset(&st, 0, sizeof(st));
   ctx->keep_row = train_row;
+  ctx->keep_h_only = 1;          // the backward covers the rollout rows only: of the bootstrap rows it reads the fc activations
   int rc;
   if (ctx->cfg.arch == PAAC_ARCH_NATURE)
     rc = forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
   else
     rc = forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
   ctx->keep_row = -1;
+  ctx->keep_h_only = 0;
   if (rc) return rc;
   ctx->heads_pending_rows = train_row + batch;
   ctx->heads_pending_splits = 1;

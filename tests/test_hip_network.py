@@ -718,12 +718,10 @@ def test_update_from_kept_acting_rows(arch, A, T, N, scale):
     assert np.abs(a["loss"] - b["loss"]).max() <= 1e-5 * max(1.0, np.abs(a["loss"]).max())
     # the kept rows against the oracle
     ref = onet.forward(params, states, arch, dtype=np.float64, keep=True)["cache"]
-    H = 512 if arch == "NATURE" else 256
     for i, got in zip(layers, b["acts"]):
-        want = ref["a%d" % i if i < 4 else "h"].reshape(-1)
-        assert got.shape == want.shape
-        if i == 4:          # fc activations: the update's B rows (the bootstrap rows' stay in the kept slab, read for v only)
-            got, want = got[:B * H], want[:B * H]
+        want = ref["a%d" % i if i < 4 else "h"]
+        want = want.reshape(B + N, -1)[:B].reshape(-1)          # the update's B rows: of the bootstrap rows only the fc
+        got = got.reshape(B + N, -1)[:B].reshape(-1)            # activations are kept (in the slab, read for v only)
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), "kept layer %d" % i
     # a forward that cannot keep its rows says so
     ctx.keep_next_forward(B)                        # rows [B, B + N + 1) do not fit the training set
