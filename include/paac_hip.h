@@ -305,7 +305,8 @@ int paac_graph_destroy(paac_graph* g);
 
 /* Test/debug: copy an internal activation to a caller device buffer (async on stream).
  * what: 1..3 = conv outputs a1..a3 [batch,OH,OW,C], 4 = fc activations h [batch,H] of the activation set used
- * last (acting or training); 11..13 / 14 = the gradients wrt them.  Returns the element count. */
+ * last (acting or training); 21..23 / 24 = the same of the TRAINING set explicitly (rows kept by paac_keep_next_forward);
+ * 11..13 / 14 = the gradients wrt them.  Returns the element count. */
 int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, paac_stream_t stream);
 
 /* Test/debug: sampler workgroup `sampler_workgroup` of paac_act_step_mt's large-shard step launch reports an exactly-zero

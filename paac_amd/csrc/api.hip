@@ -487,7 +487,9 @@ int64_t paac_debug_activation(paac_ctx* ctx, int what, int batch, float* out, pa
   PAAC_REQUIRE(ctx && out && batch > 0 && batch <= ctx->max_batch, "paac_debug_activation: bad arguments");
   const float* src = nullptr;
   int64_t n = 0;
-  const Workspace& W = ctx->ws[ctx->last_ws];
+  const bool training_set = what >= 21 && what <= 24;      // 21..24: a1..a3 / h of the TRAINING set whichever was used last
+  if (training_set) what -= 20;
+  const Workspace& W = ctx->ws[training_set ? 1 : ctx->last_ws];
   if (what >= 1 && what <= ctx->spec.nconv) {
     const ConvSpec& cs = ctx->spec.conv[what - 1];
     src = W.act[what - 1];

@@ -658,6 +658,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       p1_hi = 0;
     }
   }
+  MISC_STAMP(13);
   if constexpr (!HOOKED) phase1(p1_lo, p1_hi);
   MISC_STAMP(2);
   // phase 2: successive MT19937 state blocks

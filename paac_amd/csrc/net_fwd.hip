@@ -176,7 +176,8 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
     keep = true;
     a.act1 = keepW->act[0] + (size_t)keep_row * 400 * NatureNet::C1;
     a.act2 = keepW->act[1] + (size_t)keep_row * 81 * NatureNet::C2;
-    a.act3_rows = keepW->act[2] + (size_t)keep_row * NatureNet::FLAT;
+    if (packed3) a.act3_rows = keepW->act[2] + (size_t)keep_row * NatureNet::FLAT;      // a second copy beside the fragments
+    else a.act3 = keepW->act[2] + (size_t)keep_row * NatureNet::FLAT;                   // plain rows: the kept ones serve the fc too
   }
 #ifdef PAAC_DMM_STAMPS
   a.stamps = g_tower_stamps;
@@ -227,7 +228,8 @@ static void launch_tower2(paac_ctx* ctx, Workspace& W, const float* params, cons
   if (keepW) {
     keep = true;
     a.act1 = keepW->act[0] + (size_t)keep_row * 400 * 16;
-    a.act2_rows = keepW->act[1] + (size_t)keep_row * kT2Flat;
+    if (packed2) a.act2_rows = keepW->act[1] + (size_t)keep_row * kT2Flat;
+    else a.act2 = keepW->act[1] + (size_t)keep_row * kT2Flat;
   }
   const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
   // regions per sample: nine 3x3 regions while that stays near one round of the 256 CUs, four 5x5 up to 72 rows, else one
@@ -296,10 +298,13 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
                         !st.enabled && !trunk_only;
   Workspace* keepW = nullptr;
   if (keep_row >= 0) {
-    if (!((tower || tower2) && !keep_acts && (small_tail || mid_tail) && keep_row + batch <= ctx->max_batch)) {
-      set_error("paac_keep_next_forward: rows [%d, %d) cannot be kept -- needs the three-conv network's tower, managed weights, an "
-                "acting forward of at most %d rows and keep_row + batch <= max_batch (%d)", keep_row, keep_row + batch,
-                kFcHeadsMidRows, ctx->max_batch);
+    // (the fc + head partials routes, or -- the counter-based sampler's forwards -- the split-K fc with its per-row heads
+    // launch, which then leaves the finished fc activations in the training set instead of the acting one)
+    const bool generic_ok = !small_tail && !mid_tail && (ph.enabled || st.enabled) && !defer_heads && !trunk_only;
+    if (!((tower || tower2) && !keep_acts && (small_tail || mid_tail || generic_ok) && keep_row + batch <= ctx->max_batch)) {
+      set_error("paac_keep_next_forward: rows [%d, %d) cannot be kept -- needs a stock trunk's conv tower, managed weights, an "
+                "acting forward of at most %d rows (any size with the counter-based sampler) and keep_row + batch <= max_batch "
+                "(%d)", keep_row, keep_row + batch, kFcHeadsMidRows, ctx->max_batch);
       return -1;
     }
     keepW = &ctx->ws[1];
@@ -335,6 +340,8 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   if constexpr (NT::NCONV == 3) {
     last = W.act[2];
   }
+  if (keepW && !keep_h_only && !packed3)      // the towers wrote their plain-row output into the training set
+    last = keepW->act[NT::NCONV - 1] + (size_t)keep_row * NT::FLAT;
   if constexpr (NT::NCONV == 3) if (!tower) {
     ProfScope ps(ctx, F_CONV3_FWD, batch, s);
     constexpr int P2 = NT::G2::OPIX, P3 = NT::G3::OPIX, F3 = NT::G3::FEATS;
@@ -403,8 +410,8 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
     SynthStepArgs stl = st;
     if (stl.enabled) stl.stack_in = reinterpret_cast<const uint32_t*>(states);   // the stacks just observed
     launch_heads_fwd<NT::H>(A, dim3(stl.enabled ? batch + batch * PRE_BANDS : batch), s, (const float*)W.fc_slab, splits,
-                            (long)batch * NT::H, bf, wa, ba, wc, bc, A, W.h, W.logits, W.probs, W.values, logits, probs,
-                            values, ph, batch, stl);
+                            (long)batch * NT::H, bf, wa, ba, wc, bc, A, keepW ? keepW->fc_slab + (size_t)keep_row * NT::H : W.h,
+                            W.logits, W.probs, W.values, logits, probs, values, ph, batch, stl);
   }
   return 0;
 }

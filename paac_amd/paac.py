@@ -107,8 +107,7 @@ class DeviceRollout(object):
         # (the fused conv launches -- csrc/tower.h, csrc/tower2.h -- exist for the reference's two stock trunks)
         towered = getattr(L.network, "ARCH", None) in ("NATURE", "NIPS") and os.environ.get("PAAC_TOWER", "1") != "0"
         self.act_step_large = os.environ.get("PAAC_MT_AHEAD", "1") != "0" and N <= hip_ops.ACT_STEP_MAX_ENVS_LARGE and towered
-        self.reuse_acting = (os.environ.get("PAAC_REUSE_ACTING", "1") != "0" and sampler == "numpy"
-                             and towered and N <= hip_ops.KEEP_FORWARD_MAX_ROWS)
+        self.reuse_acting = os.environ.get("PAAC_REUSE_ACTING", "1") != "0" and towered and N <= hip_ops.KEEP_FORWARD_MAX_ROWS
         hip_ops.synth_reset(env_spec["seed"], self.env_offset, self.states[0], self.raw)
         torch.cuda.synchronize(dev)
 

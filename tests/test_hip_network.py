@@ -723,6 +723,19 @@ def test_update_from_kept_acting_rows(arch, A, T, N, scale):
         want = want.reshape(B + N, -1)[:B].reshape(-1)          # the update's B rows: of the bootstrap rows only the fc
         got = got.reshape(B + N, -1)[:B].reshape(-1)            # activations are kept (in the slab, read for v only)
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), "kept layer %d" % i
+    # the counter-based sampler's forward (split-K fc + per-row heads launch with the sampler inside) keeps its rows too:
+    # same kept activations as the fc + head partials route, to fp32 summation order
+    if N <= 64:
+        acts_i = torch.zeros(N, dtype=torch.int32, device="cuda")
+        tick = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.keep_next_forward(0)
+        ctx.forward_sample(p, s[:N], 7, tick, 0, 0, acts_i, probs=torch.zeros((N, A), device="cuda"), values=torch.zeros(N, device="cuda"))
+        torch.cuda.synchronize()
+        nl = 3 if arch == "NATURE" else 2
+        for i in list(range(1, nl + 1)):
+            got = ctx.debug_activation(20 + i, B + N).cpu().numpy().reshape(B + N, -1)[:N].reshape(-1)      # the training set
+            want = ref["a%d" % i].reshape(B + N, -1)[:N].reshape(-1)
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), "philox-kept layer %d" % i
     # a forward that cannot keep its rows says so
     ctx.keep_next_forward(B)                        # rows [B, B + N + 1) do not fit the training set
     with pytest.raises(Exception):

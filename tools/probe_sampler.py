@@ -51,5 +51,6 @@ for n, v in zip(names, acc / reps):
 print("%-32s %8.0f cycles" % ("total (entry -> end)", acc.sum() / reps))
 if walk is not None:      # stamped build: wall-clock ticks (10 ns) of the workgroup that took the last ticket
     w = st[[0, 1, 2, 3, 4, 9, 10, 11, 12, 6, 7, 8]]
+    print("  p1 split: scan + ranges %d | phase 1 proper %d (10 ns ticks)" % (st[13] - st[1], st[2] - st[13]))
     print("multi (last call, 10 ns ticks): loads %d | p1 %d | p2 %d | p3 %d | walks %d | ticket %d | fence+exits %d | chase %d "
           "| actions %d | writeback %d | bookkeeping %d" % tuple(np.diff(w)))
