@@ -249,3 +249,28 @@ def test_bench_roofline_ceiling_follows_the_recorded_instruction_mix():
     assert kind == "flop" and len(pair) == 2 and pair[0] == 2.0 * 2560 * 81 * 512 * 64 and pair[1] == 2.0 * 2560 * 400 * 256 * 32
     assert bench.mfma_ceiling(pair, (1,)) is None             # a mix that does not match the bodies: no ceiling claimed
     assert bench.family_work("clip_rmsprop", 0, "NATURE", 4, 1000)[0] == "byte"
+
+
+def test_user_architecture_specs_and_library_names():
+    """networks.py:117-120 through `--user_arch`: the two spellings (filter counts of the reference trunks' layer shapes, or
+    filters:size:stride per layer), what is refused before any compile starts, and that an architecture's layer shapes are
+    part of its library's name (two geometries never share a file)."""
+    from paac_amd import build
+    assert build.parse_user_arch("32,64,64,1024") == ([(32, 8, 4), (64, 4, 2), (64, 3, 1)], 1024)
+    assert build.parse_user_arch("16,32,256") == ([(16, 8, 4), (32, 4, 2)], 256)
+    assert build.parse_user_arch("32:8:4,64:5:2,64:3:1,512") == ([(32, 8, 4), (64, 5, 2), (64, 3, 1)], 512)
+    assert build.parse_user_arch("32:4:2,64,256") == ([(32, 4, 2), (64, 4, 2)], 256)      # spellings mix per layer
+    with pytest.raises(ValueError):
+        build.parse_user_arch("32:8,64,256")
+    stock = build.user_arch_library([(16, 8, 4), (32, 4, 2), (32, 3, 1)], 256)
+    other = build.user_arch_library([(16, 8, 4), (32, 5, 2), (32, 3, 1)], 256)
+    assert stock[0].endswith("libpaac_hip_user_16_32_32_256.so") and other[0] != stock[0] and "5x2" in other[0]
+    for convs, fc, err in [([(16, 8, 4)], 256, NotImplementedError),                      # one conv layer
+                           ([(16, 8, 4), (32, 4, 2), (32, 3, 1), (32, 3, 1)], 256, NotImplementedError),
+                           ([(24, 8, 4), (32, 4, 2)], 256, NotImplementedError),          # filters not a multiple of 16
+                           ([(16, 8, 4), (32, 4, 2)], 300, NotImplementedError),          # fc width not a multiple of 256
+                           ([(16, 5, 2), (32, 4, 2)], 256, NotImplementedError),          # first layer: 5 x 4 channels is no K group
+                           ([(16, 8, 4), (32, 4, 2), (32, 11, 1)], 256, ValueError),      # 9 x 9 in, 11 x 11 kernel: no output
+                           ([(16, 8, 0), (32, 4, 2)], 256, ValueError)]:
+        with pytest.raises(err):
+            build.build_user_arch(convs, fc)
