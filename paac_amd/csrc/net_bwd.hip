@@ -439,11 +439,19 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     for (int par = 0; par < 4; ++par) gd.tap_base[par] = (((par >> 1) + 2) * 4 + (par & 1) + 2) * NT::C1 * NT::C2;
     gd.tap_sh = -8 * NT::C1 * NT::C2;
     gd.tap_sw = -2 * NT::C1 * NT::C2;
+    // conv2's data gradient first: conv1's weight gradient (which may share the launch below with conv2's) reads it
+    if constexpr (!NT::FAMILY) {
+      ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
+      launch_dgrad_direct<typename NT::G2, NT::C2>(ctx->dact[1], w2, W.act[0], ctx->dact[0], batch, s);
+    } else if (!(NT::NCONV == 3 && ctx->tower_on)) {     // Nature with the tower: done by dgrad_tower_kernel above
+      ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
+      launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(gd, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
+    }
     int splits = 0;
     // The conv2 and conv1 weight gradients wait on the data-gradient tower only, and a workgroup of each fits a CU
     // together (two 4-wave bodies, 133 registers, 66.5 KB of LDS: 2 per CU = the 256 + 256 workgroups of the pair): one
     // launch.  conv1 runs its 4-wave configuration here (alone its 8-wave one is faster; in the pair it is not).
-    if constexpr (NT::NCONV == 3) {
+    if constexpr (NT::FAMILY) {       // (the stock NIPS geometry too: its heuristics land on the pair's configurations)
       static const bool pair_on = env_int("PAAC_WGRAD_PAIR", 1) != 0;
       const int f1 = NT::G1::FEATS;
       GemmArgs g1 = make_args(states, (size_t)batch * 28224, ctx->dact[0], (size_t)batch * P1 * NT::C1 * 4,
@@ -452,7 +460,7 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
       int c2, k2, x2, c1, k1, x1;
       resolve_wgrad<false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], c2, k2, x2);
       resolve_wgrad<true, NT::C1>(g1, W_SPLITS_MAX, ctx->tune[OP_CONV1_WGRAD][cls], c1, k1, x1);
-      if (pair_on && ctx->tower_on && c2 == 0 && c1 == kExactBf16 + 0) {
+      if (pair_on && (ctx->tower_on || ctx->tower2_on) && c2 == 0 && c1 == kExactBf16 + 0) {
         using D2 = WgradBody<typename NT::G2, false, NT::C2, 4, 4, 2>;
         using D1 = WgradBody<typename NT::G1, true, NT::C1, 4, 4, 2, 1>;
         PairArgs pa;
@@ -472,13 +480,6 @@ static int backward_impl(paac_ctx* ctx, const float* params, const uint8_t* stat
     if (splits == 0) {
       ProfScope ps(ctx, F_CONV2_WGRAD, batch, s);
       splits = launch_wgrad<typename NT::G2, false, NT::C2>(gw, W_SPLITS_MAX, ctx->tune[OP_CONV2_WGRAD][cls], s);
-    }
-    if constexpr (!NT::FAMILY) {
-      ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
-      launch_dgrad_direct<typename NT::G2, NT::C2>(ctx->dact[1], w2, W.act[0], ctx->dact[0], batch, s);
-    } else if (!(NT::NCONV == 3 && ctx->tower_on)) {     // Nature with the tower: done by dgrad_tower_kernel above
-      ProfScope ps(ctx, F_CONV2_DGRAD, batch, s);
-      launch_dgrad<typename NT::G2D, NT::C1, NT::C2, EPI_MASK_PARITY>(gd, 4, ctx->tune[OP_CONV2_DGRAD][cls], s);
     }
     wgrad_out(i_w2, feats, NT::C2, slab, splits);
     slab += (long)W_SPLITS_MAX * (feats + 1) * NT::C2;
