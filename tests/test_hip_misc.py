@@ -310,11 +310,14 @@ def test_act_step_equals_separate_calls(arch, A, N, managed):
             # tickets: make one report a zero it has not seen -- the last-ticket workgroup then finishes ALL heads and walks
             # the serial way; ordinary probabilities, so the result is unchanged
             _lib_check(ctx.lib.paac_debug_report_zero(0 if step == 2 else 3))
-        ctx.act_step_mt(p, a["s0"], a["mt"], a["act"], a["probs"], a["val"], env_seed, off, thr, a["tick"], 0, a["s1"],
-                        a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"], walk_scratch=walk)
-        if walk is not None and managed and step in (2, 6):
+        try:
+            ctx.act_step_mt(p, a["s0"], a["mt"], a["act"], a["probs"], a["val"], env_seed, off, thr, a["tick"], 0, a["s1"],
+                            a["rew"], a["msk"], a["ep_r"], a["ep_l"], a["fin"], walk_scratch=walk)
             torch.cuda.synchronize()
-            _lib_check(ctx.lib.paac_debug_report_zero(-1))
+        finally:
+            if walk is not None and managed and step in (2, 6):
+                _lib_check(ctx.lib.paac_debug_report_zero(-1))        # process-wide: never left on for the next test
+        if walk is not None and managed and step in (2, 6):
             assert int(walk[:4].view(torch.int32).item()) == 0        # the ticket word is back at 0
         ctx.forward(p, b["s0"], probs=b["probs"], values=b["val"])
         hip_ops.sample_mt(b["probs"], b["mt"], scratch, b["act"])
