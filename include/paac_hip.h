@@ -134,6 +134,8 @@ int paac_bootstrap_forward_trunk(paac_ctx* ctx, const float* params, const uint8
  * raw_scratch (nullable, [N,2,210,160] u8): path B like paac_synth_step's -- the step launch writes the step's raw screen
  * pairs there instead of shifting the stacks, and one more launch (paac_preprocess_stack's kernel: max of the two screens,
  * PIL-nearest resize, history push, reset on terminal) builds stack_out / stack_out2 from them: four launches.
+ * stack_out == NULL (with it stack_out2, raw_scratch and the four record pointers): no environment step -- forward + heads
+ * finish + sampler only, for environments that live on the host (paac.py:104-110; up to PAAC_ACT_STEP_MAX_ENVS of them).
  * Up to PAAC_ACT_STEP_MAX_ENVS environments and N*(A-1) <= 1024 draws: the three launches above.  Beyond, up to
  * PAAC_ACT_STEP_MAX_ENVS_LARGE environments and PAAC_FUSED_SAMPLE_MAX_DRAWS draws (the 128 x 18 and 256 x 4 shards):
  * paac_forward + paac_sample_mt_synth_step in one call (four launches; lend walk_scratch as there), with the sampler's

@@ -364,8 +364,28 @@ int paac_act_step_mt(paac_ctx* ctx, const float* params, const uint8_t* states, 
                      uint8_t* stack_out2, float* rewards_out, float* masks_out, float* ep_reward, int32_t* ep_len,
                      void* finished, uint8_t* raw_scratch, void* walk_scratch, int64_t walk_scratch_bytes,
                      paac_stream_t stream) {
-  PAAC_REQUIRE(ctx && params && states && mt_state && actions && probs_out && values_out && stack_out && rewards_out &&
-               masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
+  PAAC_REQUIRE(ctx && params && states && mt_state && actions && probs_out && values_out, "paac_act_step_mt: null argument");
+  if (stack_out == nullptr) {
+    // policy forward + sampler only (the environments live on the host: paac.py:104-110 without :115-116): three launches up
+    // to PAAC_ACT_STEP_MAX_ENVS environments, paac_forward + paac_sample_mt beyond
+    PAAC_REQUIRE(!stack_out2 && !raw_scratch, "paac_act_step_mt: no environment step (stack_out == NULL) takes no stack_out2 / "
+                 "raw_scratch");
+    PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS &&
+                 (int64_t)batch * (ctx->cfg.num_actions - 1) <= 1024,
+                 "paac_act_step_mt: sampling without an environment step covers up to %d environments and 1024 draws (use "
+                 "paac_forward + paac_sample_mt); got %d x %d actions", PAAC_ACT_STEP_MAX_ENVS, batch, ctx->cfg.num_actions);
+    const float *partial, *ba, *bc;
+    int ntiles;
+    int rc = launch_forward_trunk(ctx, params, states, batch, &partial, &ntiles, &ba, &bc, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = launch_sample_env_step_heads(partial, ntiles, ba, bc, probs_out, values_out, ctx->cfg.num_actions, mt_state, actions, 0, 0,
+                                      batch, 0, nullptr, 0, states, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      nullptr, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    PAAC_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  PAAC_REQUIRE(rewards_out && masks_out && ep_reward && ep_len, "paac_act_step_mt: null argument");
   PAAC_REQUIRE(batch > 0 && batch <= ctx->max_batch && batch <= PAAC_ACT_STEP_MAX_ENVS_LARGE,
                "paac_act_step_mt: batch %d outside (0, min(max_batch=%d, %d)]", batch, ctx->max_batch,
                PAAC_ACT_STEP_MAX_ENVS_LARGE);

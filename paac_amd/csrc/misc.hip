@@ -1147,8 +1147,9 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 3; ++k) stw[k] = mt_state[min((int)threadIdx.x + k * 256, 624)];
     const int e0 = threadIdx.x < N ? threadIdx.x : 0;
-    const float ep_reward0 = ep_reward[e0];
-    const int32_t ep_len0 = ep_len[e0];
+    const bool env_step = rewards_out != nullptr;          // false: policy + sampler only (host environments do the stepping)
+    const float ep_reward0 = env_step ? ep_reward[e0] : 0.f;
+    const int32_t ep_len0 = env_step ? ep_len[e0] : 0;
     // ... and the action-independent half of environment e0's bookkeeping
     const uint32_t key0 = synth_key(seed, env_offset + (uint32_t)e0, id);
     const uint32_t hr5 = synth_reward_slot(key0);
@@ -1168,7 +1169,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
                         MultiWalk{nullptr, nullptr, nullptr, 0}, ahead);
     }
     // (the sampler body ends past a barrier; its last wave is still writing the stream position back)
-    if ((int)threadIdx.x < N)       // N <= 64 here: one environment per thread
+    if (env_step && (int)threadIdx.x < N)       // N <= 64 here: one environment per thread
       synth_bookkeep_hashed(hr5, term0, e0, act_s[e0], ep_reward0, ep_len0, rewards_out, masks_out, ep_reward, ep_len, fin);
     return;
   }
@@ -1676,7 +1677,8 @@ int launch_sample_env_step_heads(const float* partial, int ntiles, const float* 
                                  const void* mt_ahead, hipStream_t s) {
   {
     ProfScope ps(g_prof_ctx, F_SAMPLE_ENV_STEP, N, s);
-    launch_k(synth_step_a_mth_kernel, dim3(1 + N * PRE_BANDS), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
+    // (stack_out == nullptr: no environment step -- workgroup 0 alone: heads finish + sampler)
+    launch_k(synth_step_a_mth_kernel, dim3(stack_out ? 1 + N * PRE_BANDS : 1), dim3(256), s, PROF_WHOLE, partial, ntiles, ba, bc, probs_out,
              values_out, A, mt_state, actions, seed, env_offset, N, thresh, step_base, step_off, (const uint32_t*)stack_in,
              (uint32_t*)stack_out, (uint32_t*)stack_out2, rewards, masks, ep_reward, ep_len, (FinishedRing*)finished,
              (uint32_t*)raw_scratch, reinterpret_cast<const MtAhead*>(mt_ahead));

@@ -239,6 +239,18 @@ class Context(object):
             int(walk_scratch.numel()) if walk_scratch is not None else 0, _stream()),
             "paac_act_step_mt")
 
+    def act_mt(self, params, states, mt_state, actions, probs_out, values_out):
+        """Policy forward + numpy-parity sampler in three launches, no environment step (paac_act_step_mt with stack_out =
+        NULL): what the host-plugin loop runs per step (paac.py:104-110).  N <= ACT_STEP_MAX_ENVS, N*(A-1) <= 1024."""
+        N, A = self._check_states(states), self.num_actions
+        z = ctypes.c_void_p(0)
+        _lib.check(self.lib.paac_act_step_mt(
+            self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),
+            _ptr(states, torch.uint8, N * 28224, "states"), N, _ptr(mt_state, torch.int32, 625, "mt_state"),
+            _ptr(actions, torch.int32, N, "actions"), _ptr(probs_out, torch.float32, N * A, "probs_out"),
+            _ptr(values_out, torch.float32, N, "values_out"), 0, 0, 0, z, 0, z, z, z, z, z, z, z, z, z, 0, _stream()),
+            "paac_act_step_mt")
+
     def pack_weights(self, params):
         """Refresh the ctx's pre-split copy of the conv weights (include/paac_hip.h: paac_pack_weights)."""
         _lib.check(self.lib.paac_pack_weights(self.handle, _ptr(params, torch.float32, self.layout["total"], "params"),

@@ -685,14 +685,54 @@ class PAACLearner(ActorLearner):
                 total_episode_rewards[e] = 0
                 emulator_steps[e] = 0
 
+        # One step's GPU work -- observations H2D, policy forward, numpy-parity sampler, action indices D2H -- as ONE hipGraph
+        # launch per step where it can be captured (page-locked shared observations, up to 64 environments on a stock trunk:
+        # paac_act_step_mt's sampling-only form, three kernels), instead of seven API calls whose host cost is what this
+        # loop is made of; PAAC_HOST_GRAPH=0, or anything that cannot be captured, keeps the eager calls
+        fused_act = (N <= hip_ops.ACT_STEP_MAX_ENVS and N * (A - 1) <= hip_ops.ACT_STEP_MAX_DRAWS
+                     and getattr(self.network, "ARCH", None) in ("NATURE", "NIPS"))
+        host_stream = torch.cuda.Stream(device=dev)
+        host_stream.wait_stream(torch.cuda.current_stream(dev))
+        step_graphs = [None] * T
+
+        def step_gpu(t):
+            d_states[t].copy_(current_states(), non_blocking=True)
+            if fused_act:
+                self.ctx.act_mt(params, d_states[t], mt_state, d_actions[t], d_probs, d_values[t])
+            else:
+                self.ctx.forward(params, d_states[t], probs=d_probs, values=d_values[t])
+                hip_ops.sample_mt(d_probs, mt_state, mt_scratch, d_actions[t])
+            h_actions.copy_(d_actions[t], non_blocking=True)
+
+        if (os.environ.get("PAAC_HOST_GRAPH", "1") != "0" and not raw_mode and pinned and fused_act):
+            with torch.cuda.stream(host_stream):
+                try:
+                    for t in range(T):
+                        g = hip_ops.Graph()
+                        g.begin()
+                        try:
+                            step_gpu(t)
+                        except Exception:
+                            g.abort()
+                            raise
+                        g.end()
+                        step_graphs[t] = g
+                except Exception as exc:      # noqa: BLE001 -- a copy or launch the runtime would not record: eager calls
+                    logging.debug("host-plugin loop: per-step graph not captured (%s), issuing the calls eagerly", exc)
+                    for g in step_graphs:
+                        if g is not None:
+                            g.close()
+                    step_graphs = [None] * T
+        ctx_stream = torch.cuda.stream(host_stream)
+        ctx_stream.__enter__()          # everything below is issued on the loop's own stream
         while self.global_step < self.max_global_steps and not parallel.any_rank(self.stop_requested, dev):
             loop_start_time = time.time()
             pending = None
             for t in range(T):
-                d_states[t].copy_(current_states(), non_blocking=True)
-                self.ctx.forward(params, d_states[t], probs=d_probs, values=d_values[t])
-                hip_ops.sample_mt(d_probs, mt_state, mt_scratch, d_actions[t])
-                h_actions.copy_(d_actions[t], non_blocking=True)
+                if step_graphs[t] is not None:
+                    step_graphs[t].launch()
+                else:
+                    step_gpu(t)
                 actions_ready.record()
                 if pending is not None:            # the previous step's records, while the GPU is busy with this step
                     bookkeeping(*pending)
@@ -740,6 +780,11 @@ class PAACLearner(ActorLearner):
                 self._progress_record(T * N * world / (curr_time - loop_start_time),
                                       (self.global_step - global_step_start) / (curr_time - start_time), last_ten)
             self.save_vars()
+        host_stream.synchronize()
+        ctx_stream.__exit__(None, None, None)
+        for g in step_graphs:
+            if g is not None:
+                g.close()
         logging.debug("Host-plugin loop: %d update cycles, global step %d", counter, self.global_step)
         np.random.set_state(hip_ops.mt_state_to_numpy(mt_state))
 
