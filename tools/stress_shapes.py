@@ -14,6 +14,11 @@ CASES = [("breakout", 1, 1, 2, "NATURE"), ("pong", 3, 2, 2, "NIPS"), ("seaquest"
          # around the batch classes of the paired weight-gradient launches (65 .. 512 training rows)
          ("breakout", 13, 5, 1, "NATURE"), ("breakout", 14, 5, 2, "NATURE"), ("qbert", 100, 5, 1, "NATURE"),
          ("breakout", 103, 5, 1, "NATURE"), ("seaquest", 27, 3, 2, "NATURE")]
+# round 4: every case also on path B (raw screen pairs + the preprocess launch), plus shapes around the large-shard routes
+# (heads finished inside the sampler workgroups up to 8 actions; doubles made ahead; kept rows at 65 .. 256 environments)
+CASES = [c + (False,) for c in CASES] + [c + (True,) for c in CASES[::3]] + [
+    ("breakout", 128, 2, 1, "NATURE", False), ("qbert", 129, 2, 1, "NATURE", False), ("seaquest", 66, 3, 1, "NATURE", False),
+    ("pong", 200, 2, 1, "NIPS", False), ("breakout", 255, 1, 1, "NATURE", True), ("qbert", 97, 2, 1, "NIPS", True)]
 bad = 0
 for c in CASES:
     try:
