@@ -64,6 +64,12 @@ struct TowerArgs {
 #define TOWER_STAMP(i)
 #endif
 
+#ifndef PAAC_T_KS2
+#define PAAC_T_KS2 2
+#endif
+#ifndef PAAC_T_KS3
+#define PAAC_T_KS3 2
+#endif
 constexpr int kTowerW1Vecs = 8 * 2 * 3 * 64, kTowerW2Vecs = 16 * 4 * 3 * 64, kTowerW3Vecs = 18 * 4 * 3 * 64;   // bf16x8 each
 constexpr int kTowerPackVecs = kTowerW1Vecs + kTowerW2Vecs + kTowerW3Vecs;
 // data-gradient weights of the backward tower (dgrad_tower.h), stored behind the forward planes in the same buffer
@@ -119,7 +125,10 @@ struct TowerGeom {
   static constexpr int PT1 = (P1 + 15) / 16, PT2 = (P2 + 15) / 16, PT3 = (P3 + 15) / 16;   // 16-pixel tiles
   static constexpr int S1 = 80, S2 = 160;                              // bytes per pixel in the conv1 / conv2 LDS planes
   static constexpr int PL1 = P1 * S1, PL2 = P2 * S2;                   // plane strides
-  static constexpr bool KSPLIT2 = (PT2 % 2) != 0, KSPLIT3 = (PT3 % 2) != 0;
+  // K split over the two waves of a channel tile (else the pixel tiles are): forced when the tiles do not halve -- and for
+  // the small regions, where a weight fragment fetched by BOTH waves for one or two pixel tiles each makes the layer wait
+  // for the CU's L1 (stamped at 32 rows: conv2 6.4 k cycles for 3.1 k of MFMA issue, 392 KB of fragments through the L1)
+  static constexpr bool KSPLIT2 = (PT2 % 2) != 0 || PT2 <= PAAC_T_KS2, KSPLIT3 = (PT3 % 2) != 0 || PT3 <= PAAC_T_KS3;
   static constexpr int NT1 = (PT1 + 3) / 4;                            // conv1: pixel tiles per wave (4 pixel groups x 2 channel tiles)
   static constexpr int NT2 = KSPLIT2 ? PT2 : PT2 / 2, NT3 = KSPLIT3 ? PT3 : PT3 / 2;
   // weight prefetch depth per layer (k-steps ahead); a depth >= the k-step count loads every fragment up front

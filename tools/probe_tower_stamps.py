@@ -24,10 +24,13 @@ ctx.pack_weights(P)
 for _ in range(20):
     ctx.forward(P, S, probs=probs)
 torch.cuda.synchronize()
-stamps = torch.zeros(12 * 8 * 4 * B + 1024, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(12 * 8 * 9 * B + 1024, dtype=torch.int64, device="cuda")
 lib.paac_debug_set_tower_stamps(ctypes.c_void_p(stamps.data_ptr()))
+keep = os.environ.get("PROBE_KEEP", "0") == "1"
 for rep in range(3):
     stamps.zero_()
+    if keep:
+        ctx.keep_next_forward(0)
     ctx.forward(P, S, probs=probs)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy()[:-1024].reshape(-1, 12)
