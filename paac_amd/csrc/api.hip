@@ -210,6 +210,7 @@ int paac_create(const paac_cfg* cfg, paac_ctx** out) {
   {
     const char* v = getenv("PAAC_TOWER");
     c->tower_on = (cfg->arch == PAAC_ARCH_NATURE) && !(v && *v && atoi(v) == 0);
+    { const char* q = getenv("PAAC_FC_QUARTER"); c->no_quarter_tiles = (q && *q && atoi(q) == 0) ? 1 : 0; }
     c->tower2_on = (cfg->arch == PAAC_ARCH_NIPS) && tower2_available() && !(v && *v && atoi(v) == 0);
     c->managed_weights = 0;
     c->tower_pack = nullptr;

@@ -138,6 +138,8 @@ struct paac_ctx {
   void* tower_pack;      // kTowerPackVecs x 16 bytes, nullptr when the tower is off
   void* fc_pack;         // fc weights in fc_heads_kernel's fragment order (flat * H floats)
   int tower_on;          // PAAC_TOWER (default 1)
+  int heads_ntiles;      // column groups of the last fc + head-partials launch (fc_heads.h: 16- or 8-wide tiles)
+  int no_quarter_tiles;  // PAAC_FC_QUARTER=0: always whole 16 x 16 tiles (A/B measurements)
   int tower2_on;         // the two-conv tower of the stock NIPS geometry (csrc/tower2.h), same knob
   int managed_weights;   // paac_set_managed_weights: 1 = the caller keeps tower_pack current (paac_clip_rmsprop / paac_pack_weights
                          // re-pack) and acting forwards keep no conv1 / conv2 activations; 0 = every forward re-packs first

@@ -151,6 +151,112 @@ __global__ __launch_bounds__(64 * NW) void fc_heads_kernel(const float* __restri
   }
 }
 
+// Quarter tiles for the smallest batches: a workgroup owns 8 rows x 8 fc columns, 256 workgroups at 32 rows of the stock
+// width -- one per CU, 200 KB each through its L1 instead of 64 workgroups of 400 KB.  Every lane still loads 16 useful
+// bytes per operand and K group: lanes li < 8 feed the MFMA rows / columns 0..7 with K group 2 i, lanes li >= 8 feed rows /
+// columns 8..15 with THE SAME 8 rows / columns at K group 2 i + 1 -- the diagonal blocks D[0..7][0..7] and D[8..15][8..15]
+// are then the tile's partial sums over the even and the odd K groups (the off-diagonal blocks mix the two and are dropped):
+// half of the matrix pipe's work is thrown away, in a layer that keeps it 8 % busy.  (Masking the upper lanes instead --
+// zeros, no loads -- was measured SLOWER than whole tiles, 9.45 against 8.1 us: a load instruction occupies the L1 for
+// the same time whatever its lane mask.)
+template <int K, int H, int NW, bool A_PACKED>
+__global__ __launch_bounds__(64 * NW) void fc_heads_q_kernel(const float* __restrict__ act, const f32x4* __restrict__ wfp,
+                                                             const float* __restrict__ bf, const float* __restrict__ Wa,
+                                                             const float* __restrict__ Wc, const int A, const int B,
+                                                             float* __restrict__ partial, float* __restrict__ h_out) {
+  constexpr int NTILES = H / 8, G = K / 16, GPW = G / NW, NS = GPW / 2, PF = 6;
+  static_assert(K % 16 == 0 && H % 16 == 0 && G % NW == 0 && GPW % 2 == 0 && NS > PF, "fc geometry");
+  __shared__ f32x4 red[NW * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int l8 = li & 7, odd = li >> 3;                 // position inside the 8-wide tile; which K group of a pair this lane feeds
+  const int nt = blockIdx.x % NTILES, mt = blockIdx.x / NTILES;
+  const int row_a = mt * 8 + l8;                        // A operand: this lane's row
+  const bool row_ok = row_a < B;
+  const int col = nt * 8 + l8;                          // B operand / D: this lane's column
+  // per-pair stride of the A fragment pointer: 32 floats along a row, or two 64-lane x 4-float blocks
+  constexpr int A_STEP = A_PACKED ? 512 : 32;
+  const int g0 = wave * GPW + odd;                      // this lane's first K group
+  const float* ap = A_PACKED ? act + ((((size_t)(mt >> 1) * G + g0) * 64) + kq * 16 + (mt & 1) * 8 + l8) * 4
+                             : act + (size_t)(row_ok ? row_a : 0) * K + 4 * kq + (size_t)g0 * 16;
+  const f32x4* bp = wfp + ((size_t)(nt >> 1) * G + g0) * 64 + kq * 16 + (nt & 1) * 8 + l8;
+
+  constexpr int RING = PF + 1;
+  f32x4 fa[RING], fb[RING];
+  constexpr int NO = (33 + NW - 1) / NW;
+  float wh[NO];
+#pragma unroll
+  for (int q = 0; q < NO; ++q) {
+    const int o = wave + NW * q;
+    wh[q] = (o < A) ? Wa[(size_t)col * A + o] : (o == A ? Wc[col] : 0.f);
+  }
+  const float bias = bf[col];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    fa[i] = *reinterpret_cast<const f32x4*>(ap + A_STEP * i);
+    fb[i] = bp[(size_t)i * 128];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    if (i + PF < NS) {
+      fa[(i + PF) % RING] = *reinterpret_cast<const f32x4*>(ap + A_STEP * (i + PF));
+      fb[(i + PF) % RING] = bp[(size_t)(i + PF) * 128];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(row_ok ? fa[i % RING][e] : 0.f, fb[i % RING][e], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  // D layout: lane (li, kq) holds rows 4 kq + r of column li.  The tile's sums: even groups at (li < 8, kq < 2), odd groups at
+  // (li + 8, kq + 2) = 40 lanes further on.  Every wave rebuilds the tile in the same fixed order.
+  const bool own = li < 8 && kq < 2;
+  const int src = own ? lane : 0;
+  f32x4 h = red[src] + red[src + 40];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) h += red[w * 64 + src] + red[w * 64 + src + 40];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h[r] = own ? fmaxf(h[r] + bias, 0.f) : 0.f;     // rows 4 kq + r (kq < 2), column li
+  if (h_out != nullptr && wave == 0 && own) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = mt * 8 + 4 * kq + r;
+      if (row < B) h_out[(size_t)row * H + col] = h[r];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NO; ++q) {
+    const int o = wave + NW * q;
+    if (o > A) break;                                  // wave-uniform
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = h[r] * wh[q];
+      t += __shfl_xor(t, 1, 64);                       // sum over the 8 columns of the tile (lanes li < 8 of one kq)
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      v[r] = t;
+    }
+    if (li == 0 && kq < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 8 + 4 * kq + r;
+        if (row < B) partial[((size_t)nt * B + row) * (A + 1) + o] = v[r];
+      }
+    }
+  }
+}
+// does the quarter-tile kernel exist for this geometry (the waves' K groups must pair up)?
+constexpr bool fc_heads_quarter_ok(const int flat) {
+  const int w = fc_heads_waves(flat);
+  return w > 0 && (flat / 16 / w) % 2 == 0 && (flat / 16 / w) / 2 > 6;
+}
+
 // Second half of the heads finish: logits of all B rows in lg_s -> softmax, stores.  Ends with a barrier.
 __device__ __forceinline__ void heads_softmax_store(const int B, const int A, const float* lg_s, float* probs_lds,
                                                     float* __restrict__ logits_out, float* __restrict__ probs_out,
@@ -208,26 +314,28 @@ __device__ __forceinline__ void heads_from_partials(const float* __restrict__ pa
 
 // The same in two halves for a caller with something to do while the partial loads travel; B (A + 1) <= 256: one (row,
 // output) per thread.  Same sums in the same order as heads_from_partials.
+template <int NV>
 __device__ __forceinline__ void heads_partials_issue(const float* __restrict__ partial, const int ntiles, const int n,
                                                      const int A, const float* __restrict__ ba,
-                                                     const float* __restrict__ bc, float (&v)[32], float& bias) {
+                                                     const float* __restrict__ bc, float (&v)[NV], float& bias) {
   const int idx = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
   const int a = idx % (A + 1);
   bias = (a < A) ? ba[a] : bc[0];
 #pragma unroll
-  for (int t = 0; t < 32; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];
+  for (int t = 0; t < NV; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];
 }
-// (tiles beyond the 32 issued ones -- fc widths beyond 512 -- are read here, in the same order)
-__device__ __forceinline__ void heads_from_issued(const float (&v)[32], const float bias, const float* __restrict__ partial,
+// (tiles beyond the NV issued ones -- fc widths beyond 512 -- are read here, in the same order)
+template <int NV>
+__device__ __forceinline__ void heads_from_issued(const float (&v)[NV], const float bias, const float* __restrict__ partial,
                                                   const int ntiles, const int B, const int A, float* lg_s, float* probs_lds,
                                                   float* __restrict__ probs_out, float* __restrict__ values_out) {
   float acc = bias;
 #pragma unroll
-  for (int t = 0; t < 32; ++t) acc += (t < ntiles) ? v[t] : 0.f;
-  if (ntiles > 32) {
+  for (int t = 0; t < NV; ++t) acc += (t < ntiles) ? v[t] : 0.f;
+  if (ntiles > NV) {
     const int n = B * (A + 1);
     const int idx = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
-    for (int t0 = 32; t0 < ntiles; t0 += 32) {
+    for (int t0 = NV; t0 < ntiles; t0 += 32) {
       float w[32];
 #pragma unroll
       for (int t = 0; t < 32; ++t) w[t] = partial[(size_t)(t0 + t < ntiles ? t0 + t : 0) * n + idx];

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
     if (N * (A + 1) <= 256) {
       // one (row, output) per thread: the partials are requested now and summed after the sampler's state blocks and
       // doubles, which need nothing but the state words -- the loads travel while those phases compute
-      float pv[32], bias;
+      float pv[64], bias;      // (quarter-tile fc launches leave 64 partials per output at the stock fc width)
       heads_partials_issue(partial, ntiles, N * (A + 1), A, ba, bc, pv, bias);
       auto finish_heads = [&]() { heads_from_issued(pv, bias, partial, ntiles, N, A, lg_s, probs_sh, probs_out, values_out); };
       sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, finish_heads,

@@ -353,7 +353,11 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
   // head finish -- as its own one-workgroup launch here, or (defer_heads) inside the caller's sampler launch.
   if constexpr (NW > 0) if (small_tail || mid_tail) {
     if (wsi == 1) ctx->heads_pending_rows = 0;
-    constexpr int NTILES = NT::H / 16;
+    // quarter tiles (fc_heads.h) while they fit one workgroup per CU: 32 rows of the stock fc width = 256 workgroups
+    const bool quarter = fc_heads_quarter_ok(NT::FLAT) && ((batch + 7) / 8) * (NT::H / 8) <= 256 && !ctx->no_quarter_tiles &&
+                         ctx->ahead_state == nullptr;
+    const int NTILES = quarter ? NT::H / 8 : NT::H / 16;
+    ctx->heads_ntiles = NTILES;
     float* partial = W.fc_slab;      // [NTILES][batch][A + 1]: fits the split-K slab buffer
     const bool keep_h = keep_acts;
     // kept rows: the finished fc activations (bias + ReLU applied) go where the training forward's fc slabs would be
@@ -365,7 +369,17 @@ static int forward_impl(paac_ctx* ctx, int wsi, const float* params, const uint8
       MtAheadArgs ah{ctx->ahead_state, ctx->ahead_state ? reinterpret_cast<MtAhead*>(ctx->mt_ahead) : nullptr, ctx->ahead_D};
       ctx->ahead_state = nullptr;
       const unsigned grid = NTILES * ((batch + 15) / 16) + (ah.out ? 1 : 0);
-      if (packed3)
+      if constexpr (fc_heads_quarter_ok(NT::FLAT)) if (quarter) {
+        if (packed3)
+          launch_k(fc_heads_q_kernel<NT::FLAT, NT::H, NW, true>, dim3(NTILES * ((batch + 7) / 8)), dim3(64 * NW), s, PROF_WHOLE,
+                   last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, h_keep);
+        else
+          launch_k(fc_heads_q_kernel<NT::FLAT, NT::H, NW, false>, dim3(NTILES * ((batch + 7) / 8)), dim3(64 * NW), s, PROF_WHOLE,
+                   last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial,
+                   keep_h ? W.h : (float*)nullptr);
+      }
+      if (quarter) {
+      } else if (packed3)
         launch_k(fc_heads_kernel<NT::FLAT, NT::H, NW, true>, dim3(grid), dim3(64 * NW), s, PROF_WHOLE,
                  last, reinterpret_cast<const f32x4*>(ctx->fc_pack), bf, wa, wc, A, batch, partial, h_keep, ah);
       else
@@ -480,10 +494,11 @@ int launch_forward_trunk(paac_ctx* ctx, const float* params, const uint8_t* stat
   *ba = params + L.offset[nt - 3];
   *bc = params + L.offset[nt - 1];
   *partial = ctx->ws[0].fc_slab;
-  *ntiles = ctx->spec.fc / 16;
-  if (ctx->cfg.arch == PAAC_ARCH_NATURE)
-    return forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
-  return forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+  const int rc = (ctx->cfg.arch == PAAC_ARCH_NATURE)
+                     ? forward_impl<NatureNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true)
+                     : forward_impl<OtherNet>(ctx, 0, params, states, batch, nullptr, nullptr, nullptr, ph, st, s, true);
+  *ntiles = ctx->heads_ntiles;       // (this launch's: whole or quarter tiles, fc_heads.h)
+  return rc;
 }
 
 // Acting-shaped forward of the N bootstrap observations whose rows complete a training set the acting steps have kept

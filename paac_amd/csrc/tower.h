@@ -218,13 +218,18 @@ struct WaveGemm {
       __builtin_amdgcn_sched_barrier(0);
       const int slot = i % RING;
       constexpr int NB = DB ? 2 : 1;
+      if constexpr (BP == 1) {
+        // smallest terms first; plane-major, so that consecutive MFMAs are independent (a lone wave on its SIMD has no
+        // partner to fill the slots between dependent ones)
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a[slot][pl], b[i % NB][t][0], acc[t]);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const bf16x8(&bt)[BP] = b[i % NB][t];
         if constexpr (BP == 1) {
-          acc[t] = mfma_bf16(a[slot][2], bt[0], acc[t]);   // smallest terms first
-          acc[t] = mfma_bf16(a[slot][1], bt[0], acc[t]);
-          acc[t] = mfma_bf16(a[slot][0], bt[0], acc[t]);
         } else {
           acc[t] = mfma_bf16(a[slot][2], bt[0], acc[t]);
           acc[t] = mfma_bf16(a[slot][1], bt[1], acc[t]);
@@ -370,11 +375,21 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs p) {
     for (int j = 0; j < G::NT1; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + 16 * ct + 4 * kq);
     if constexpr (G::W1_LDS) {
-      // conv2's weight fragments stream in while conv1 computes (conv1's own weights come from LDS: the registers are free)
-      g2.prologue(p.w2p + lane, wave & 3, 1, G::KSPLIT2 ? 8 * (wave >> 2) : 0);
+      // conv2's weight fragments stream in while conv1 computes (conv1's own weights come from LDS: the registers are
+      // free), one k-step's per k-step of conv1: 8 waves x 24 fragment loads are 3 k cycles of the CU's load path and a wave
+      // cannot issue past a full queue -- requested all at once in front of conv1's GEMM they held its first MFMAs back
+      // (tower 10.9 -> 10.5 us at 32 rows).  Requested earlier still, behind the staging loads, they delay the image
+      // instead (staging 1.6 k -> 4 k cycles, with or without a barrier between the two groups of requests); and four
+      // waves of 4-5 pixel tiles instead of eight of 2-3 (less LDS traffic for the weight fragments) measured equal.
+      g2.set(p.w2p + lane, wave & 3, 1, G::KSPLIT2 ? 8 * (wave >> 2) : 0);
       g1.prologue(reinterpret_cast<const bf16x8*>(lds_w1) + lane, ct, 1, 0);
+      g1.run(lds_in, bb, acc, [&](const int i) { g2.prologue_step(i); });
+#pragma unroll
+      for (int j = 8; j < decltype(g2)::PF; ++j) g2.prologue_step(j);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      g1.run(lds_in, bb, acc);
     }
-    g1.run(lds_in, bb, acc);
     TOWER_STAMP(4);
     if constexpr (!G::W1_LDS)   // conv2's first weights: ahead of the epilogue + barrier (W1_LDS: requested before conv1's GEMM)
       g2.prologue(p.w2p + lane, wave & 3, 1, G::KSPLIT2 ? 8 * (wave >> 2) : 0);

@@ -35,34 +35,44 @@ def build_learner(args, params_seed=0):
     return learner, params, env_creator
 
 
-def oracle_cycles(args, params, env_creator, cycles, arch):
-    """The reference loop restated on the CPU: same envs, same np.random sampler stream, fp32-param / fp64-math net."""
-    A, N, T = args.num_actions, args.emulator_counts, args.max_local_steps
-    envs = [env_creator.create_environment(i) for i in range(N)]
-    rs = np.random.RandomState(args.test_seed)
-    p = {k: v.copy() for k, v in params.items()}
-    ms, mom = onet.rmsprop_init(p)
+class OracleLoop:
+    """The reference loop restated on the CPU: same envs, same np.random sampler stream, fp32-param / fp64-math net.
+    `p`, `ms`, `mom` ({tensor name: array}) may be replaced between cycles (the long device-loop case restarts every cycle
+    from the weights and optimizer slots the device really holds)."""
 
-    def policy_fn(states):
-        out = onet.forward(p, states, arch, dtype=np.float64)
-        return out["v"].astype(np.float32), out["pi"].astype(np.float32)
+    def __init__(self, args, params, env_creator, arch):
+        self.args, self.arch = args, arch
+        A, N, T = args.num_actions, args.emulator_counts, args.max_local_steps
+        envs = [env_creator.create_environment(i) for i in range(N)]
+        self.rs = np.random.RandomState(args.test_seed)
+        self.p = {k: v.copy() for k, v in params.items()}
+        self.ms, self.mom = onet.rmsprop_init(self.p)
 
-    ro = oroll.OracleRollout(envs, A, T, args.gamma, args.initial_lr, args.lr_annealing_steps, policy_fn,
-                             lambda pi: osamp.sample_mt_restated(pi, rs)[0])
-    outs = []
-    for _ in range(cycles):
-        cyc = ro.cycle()
-        L, g = onet.loss_and_grads(p, cyc["states"], cyc["actions"], cyc["y"].astype(np.float32),
-                                   cyc["adv"].astype(np.float32), args.entropy_regularisation_strength, arch,
+        def policy_fn(states):
+            out = onet.forward(self.p, states, arch, dtype=np.float64)
+            return out["v"].astype(np.float32), out["pi"].astype(np.float32)
+
+        self.ro = oroll.OracleRollout(envs, A, T, args.gamma, args.initial_lr, args.lr_annealing_steps, policy_fn,
+                                      lambda pi: osamp.sample_mt_restated(pi, self.rs)[0])
+
+    def cycle(self):
+        args = self.args
+        cyc = self.ro.cycle()
+        L, g = onet.loss_and_grads(self.p, cyc["states"], cyc["actions"], cyc["y"].astype(np.float32),
+                                   cyc["adv"].astype(np.float32), args.entropy_regularisation_strength, self.arch,
                                    dtype=np.float64)
         gc, gn = onet.clip_by_global_norm(g, args.clip_norm, args.clip_norm_type)
-        p, ms, mom = onet.rmsprop_step(p, {k: v.astype(np.float32) for k, v in gc.items()}, ms, mom,
-                                       np.float32(cyc["lr"]), args.alpha, 0.0, args.e)
-        cyc["params"] = {k: v.copy() for k, v in p.items()}
+        self.p, self.ms, self.mom = onet.rmsprop_step(self.p, {k: v.astype(np.float32) for k, v in gc.items()}, self.ms,
+                                                      self.mom, np.float32(cyc["lr"]), args.alpha, 0.0, args.e)
+        cyc["params"] = {k: v.copy() for k, v in self.p.items()}
         cyc["gnorm"] = gn
-        cyc["episodes"] = list(ro.finished_episodes)        # (global_step, reward, length) so far: paac.py:130-135
-        outs.append(cyc)
-    return outs
+        cyc["episodes"] = list(self.ro.finished_episodes)        # (global_step, reward, length) so far: paac.py:130-135
+        return cyc
+
+
+def oracle_cycles(args, params, env_creator, cycles, arch):
+    loop = OracleLoop(args, params, env_creator, arch)
+    return [loop.cycle() for _ in range(cycles)]
 
 
 @pytest.mark.parametrize("game,arch,N,T", [("pong", "NIPS", 8, 5), ("breakout", "NATURE", 8, 5)])
@@ -169,17 +179,35 @@ def test_device_loop_matches_oracle(game, N, T, cycles, arch, raw):
     np.random.seed(args.test_seed)
     learner.global_step = learner.init_network()
     ro = DeviceRollout(learner, env_creator.device_env_spec, sampler="numpy", use_graph=True)
-    want = oracle_cycles(args, params, env_creator, cycles, arch)
+    # Up to a few cycles the oracle runs on its own from the initial weights.  The LONG case restarts the oracle every cycle
+    # from the weights and RMSProp slots the device really holds: the derivative of a ReLU network is discontinuous, so an
+    # fp32 pre-activation that lands on the other side of 0 than the float64 one (a handful per million units and cycle)
+    # moves a few weights by ~1e-6, and at lr 0.0224 the two trajectories then drift apart by a factor of 1.3-3 per update
+    # whatever the kernels do (tools/probe_quarter.py prints the free-running drift: 1e-8 -> 1e-4..1e-3 over 20 cycles, a
+    # different curve for every summation order).  Restarted, EVERY cycle is held to the single-cycle bars, at the weights
+    # the run has really reached.
+    forced = cycles > 5
+    loop = OracleLoop(args, params, env_creator, arch)
+    want = []
     for c in range(cycles):
+        if forced:
+            loop.p = learner.network.get_parameters()
+            loop.ms = learner.network.get_parameters(learner.rms)
+            loop.mom = learner.network.get_parameters(learner.mom)
+        want.append(loop.cycle())
         ro.run_cycle()
         ro.synchronize()
         assert np.array_equal(ro.actions.view(-1).cpu().numpy(), np.argmax(want[c]["actions"], axis=1)), "cycle %d" % c
         assert np.array_equal(ro.rollout_states().cpu().numpy(), want[c]["states"]), "cycle %d" % c
-        assert np.abs(ro.values.cpu().numpy() - want[c]["values"]).max() < 1e-4
+        assert np.abs(ro.values.cpu().numpy() - want[c]["values"]).max() < 1e-4, "cycle %d" % c
         assert np.abs(ro.y.cpu().numpy() - want[c]["y"]).max() < 2e-4
         assert np.abs(ro.adv.cpu().numpy() - want[c]["adv"]).max() < 3e-4
         assert float(learner.lr_dev.item()) == float(np.float32(want[c]["lr"]))
         assert int(ro.global_step_dev.item()) == want[c]["global_step"]
+        if forced:        # one update from the same weights: the bar of a single step (a flipped unit moves a weight by ~1e-6)
+            got = learner.network.get_parameters()
+            for k, v in want[c]["params"].items():
+                assert np.abs(got[k] - v).max() < 2e-5, "cycle %d: %s" % (c, k)
     got = learner.network.get_parameters()
     for k, v in want[-1]["params"].items():
         assert np.abs(got[k] - v).max() < 2e-4, k
