@@ -11,10 +11,12 @@ RMSProp, on synthetic 84x84x4 uint8 frames generated on the device; value = env-
 slowest rank's wall time (weak scaling: 32 envs per GPU).  Workload at N=1 = BASELINE configs[1]
 (Breakout action set, Nature net, 32 envs, t_max=5).
 
-The timed region is repeated: `--windows` (default 9) consecutive windows of exactly K steps, each bracketed by
-barrier + synchronize on both sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN window's
-(a 20-step window is 5 ms and the clock is still ramping through the first two or three of them: one window alone is at
-the mercy of that ramp), all windows are listed in `windows_ms`.
+The timed region is repeated: consecutive windows of exactly K steps, each bracketed by barrier + synchronize on both
+sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN window's, all windows are listed in
+`windows_ms`.  `--windows` fixes their number; by default there are at least 9 and as many more as it takes to time a
+quarter of a second (at most 51): a 20-step window is 4.5 ms and the GPU clock is still ramping through the first three
+or four of them, so with nine short windows the median itself sat on the ramp (707 k against 719 k from 300-step windows
+on the same box).
 
 Extra objects on the JSON line:
   roofline     -- the kernel family with the largest share of the cycle, timed with HIP events attached to the
@@ -136,7 +138,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--windows", type=int, default=9, help="consecutive K-step windows; the median one is reported")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="consecutive K-step windows, the median one is reported; 0 = at least 9, more while they add up to "
+                         "less than 0.25 s (at most 51)")
     ap.add_argument("--host-envs", action="store_true",
                     help="also time the host-plugin loop (PCIe-inclusive) on the same workload; reported beside value")
     a = ap.parse_args()
@@ -233,7 +237,11 @@ def main():
 
     check_replicas(True)
     windows = []
-    for _ in range(max(1, a.windows)):
+    while True:
+        if a.windows > 0 and len(windows) >= a.windows:
+            break
+        if a.windows <= 0 and len(windows) >= 9 and (sum(windows) >= 0.25 or len(windows) >= 51):
+            break                       # (the window times are already MAX-reduced: every rank stops at the same count)
         barrier()
         t0 = time.perf_counter()
         ro.run_cycles(a.steps)          # exactly K cycles (graph replay batches them 4 per launch where it can)

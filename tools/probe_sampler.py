@@ -33,8 +33,17 @@ names = ["entry->loads landed", "phase 1 (cond. probabilities)", "phase 2 (state
          "table fill", "chase", "write-back", "bookkeeping"]
 acc = np.zeros(8)
 reps = 50
+fam = {}
+if ctx is not None:
+    ctx.prof_enable(True)
+# PROBE_EVICT=1: 96 MB written and a few other kernels run between the steps -- what the first step of a cycle finds after
+# the update (its L2 lines and instruction cache lines gone)
+evict = torch.zeros(24 * 1024 * 1024, device=dev) if os.environ.get("PROBE_EVICT", "") == "1" else None
 for r in range(reps + 5):
     probs = torch.softmax(torch.randn(N, A, device=dev), dim=1)    # cold-ish probabilities each time
+    if evict is not None:
+        evict.add_(1.0)
+        (evict[:1 << 20].view(1024, 1024) @ evict[1 << 20:2 << 20].view(1024, 1024)).sum()
     torch.cuda.synchronize()
     if ctx is not None:
         ctx.act_step_mt(params, s0, mt, act, pr_out, val, 3, 0, terminal_threshold(0.01), tick, 0, s1, rew, msk, epr, epl, fin,
@@ -44,11 +53,15 @@ for r in range(reps + 5):
                                      walk_scratch=walk)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().astype(np.float64)
+    if ctx is not None and r >= 5:
+        for name, batch, ms in ctx.prof_read():
+            fam[name] = fam.get(name, 0.0) + ms * 1000.0 / reps
     if r >= 5:
         acc += np.diff(st[:9])
 for n, v in zip(names, acc / reps):
     print("%-32s %8.0f cycles" % (n, v))
 print("%-32s %8.0f cycles" % ("total (entry -> end)", acc.sum() / reps))
+print("launch durations (HIP events on the dispatches), us:", {k: round(v, 2) for k, v in fam.items()})
 if walk is not None:      # stamped build: wall-clock ticks (10 ns) of the workgroup that took the last ticket
     w = st[[0, 1, 2, 3, 4, 9, 10, 11, 12, 6, 7, 8]]
     print("  p1 split: scan + ranges %d | phase 1 proper %d (10 ns ticks)" % (st[13] - st[1], st[2] - st[13]))
