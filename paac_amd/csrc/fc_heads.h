@@ -1,12 +1,14 @@
-// Acting-path tail of the network for small batches (<= 64 rows): the fc layer (networks.py:49-60) with the head
+// Acting-path tail of the network for acting batches (<= 256 rows): the fc layer (networks.py:49-60) with the head
 // contractions (policy_v_network.py:24-26) folded into its epilogue, and the head finish (bias, softmax).
 //
+//   fc_heads_q_kernel    the same on quarter tiles, (8 rows, 8 fc columns) per workgroup, while those are at most one
+//                        workgroup per CU (32 rows of the stock fc widths): half the bytes through each CU's L1, see below
 //   fc_heads_kernel      one workgroup per (16 rows, 16 fc columns): full K inside the workgroup (7 or 9 waves split K evenly, summed
 //                        through LDS), so bias + ReLU apply to complete sums and NO split-K slab leaves the workgroup; its
 //                        epilogue multiplies the 16x16 tile of h with the matching 16 rows of the actor / critic weights
 //                        and writes the tile's share of every logit and of the value: partial[tile][row][A + 1] -- a few
 //                        hundred bytes per workgroup instead of the 64 KB of h the heads used to re-read per step.
-//   heads_from_partials  device routine, one workgroup: sums the 32 (H / 16) partials per (row, output) in fixed order,
+//   heads_from_partials  device routine, one workgroup: sums the H / 16 (or H / 8) partials per (row, output) in fixed order,
 //                        adds the head biases, softmax.  Called by the stand-alone heads_finish_kernel (paac_forward) and
 //                        by workgroup 0 of the fused sampler + environment-step launch (csrc/misc.hip), which leaves the
 //                        probabilities in LDS for the sampler: the acting step is three launches (conv tower, fc + head
