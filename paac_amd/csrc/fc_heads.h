@@ -314,42 +314,6 @@ __device__ __forceinline__ void heads_from_partials(const float* __restrict__ pa
   heads_softmax_store(B, A, lg_s, probs_lds, logits_out, probs_out, values_out, logits_out2, probs_out2, values_out2);
 }
 
-// The same in two halves for a caller with something to do while the partial loads travel; B (A + 1) <= 256: one (row,
-// output) per thread.  Same sums in the same order as heads_from_partials.
-template <int NV>
-__device__ __forceinline__ void heads_partials_issue(const float* __restrict__ partial, const int ntiles, const int n,
-                                                     const int A, const float* __restrict__ ba,
-                                                     const float* __restrict__ bc, float (&v)[NV], float& bias) {
-  const int idx = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
-  const int a = idx % (A + 1);
-  bias = (a < A) ? ba[a] : bc[0];
-#pragma unroll
-  for (int t = 0; t < NV; ++t) v[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];
-}
-// (tiles beyond the NV issued ones -- fc widths beyond 512 -- are read here, in the same order)
-template <int NV>
-__device__ __forceinline__ void heads_from_issued(const float (&v)[NV], const float bias, const float* __restrict__ partial,
-                                                  const int ntiles, const int B, const int A, float* lg_s, float* probs_lds,
-                                                  float* __restrict__ probs_out, float* __restrict__ values_out) {
-  float acc = bias;
-#pragma unroll
-  for (int t = 0; t < NV; ++t) acc += (t < ntiles) ? v[t] : 0.f;
-  if (ntiles > NV) {
-    const int n = B * (A + 1);
-    const int idx = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
-    for (int t0 = NV; t0 < ntiles; t0 += 32) {
-      float w[32];
-#pragma unroll
-      for (int t = 0; t < 32; ++t) w[t] = partial[(size_t)(t0 + t < ntiles ? t0 + t : 0) * n + idx];
-#pragma unroll
-      for (int t = 0; t < 32; ++t) acc += (t0 + t < ntiles) ? w[t] : 0.f;
-    }
-  }
-  if ((int)threadIdx.x < B * (A + 1)) lg_s[threadIdx.x] = acc;
-  __syncthreads();
-  heads_softmax_store(B, A, lg_s, probs_lds, nullptr, probs_out, values_out, nullptr, nullptr, nullptr);
-}
-
 static __global__ __launch_bounds__(256) void heads_finish_kernel(const float* __restrict__ partial, int ntiles, int B, int A,
                                                            const float* __restrict__ ba, const float* __restrict__ bc,
                                                            float* __restrict__ logits_ws, float* __restrict__ probs_ws,

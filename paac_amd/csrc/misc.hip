@@ -526,6 +526,62 @@ struct RowsHeadsHook {
 };
 template <class H> struct HookOwnRows { static constexpr bool value = false; };
 template <> struct HookOwnRows<RowsHeadsHook> { static constexpr bool value = true; };
+// The small shards' hook (up to 32 environments x 7 actions, the headline shape): heads finish AND phase 1 without leaving
+// the registers.  Thread (row = tid >> 3, a = tid & 7) owns output a of environment row (a < A: a logit, a == A: the value):
+// it sums its partials (requested by the caller before the sampler's own phases), gathers its row's logits from the seven
+// neighbouring lanes, takes the softmax exactly as heads_softmax_store does (same operations in the same order: same bits),
+// gathers the row's probabilities the same way and forms its conditional probability exactly as phase 1 does -- no LDS
+// round trip and no barrier between the partial sums and the thresholds (the separate hook + phase 1 take three).
+// Leaves probs in probs_lds / probs_out, values in values_out, pj_buf / thr_s / *any_zero as phase 1 would; NO barrier.
+struct FusedHeadsHook {
+  const float (&pv)[64];
+  float bias;
+  int ntiles, N, A;
+  float* probs_lds;
+  float* probs_out;
+  float* values_out;
+  __device__ __forceinline__ void operator()(double* pj_buf, double* thr_s, int* any_zero) const {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int row = tid >> 3, a = tid & 7, J = A - 1;
+    const bool rv = row < N;
+    float acc = bias;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) acc += (t < ntiles) ? pv[t] : 0.f;
+    float lg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lg[j] = __shfl(acc, (lane & ~7) | j, 64);
+    float m = lg[0];
+#pragma unroll
+    for (int j = 1; j < 7; ++j)
+      if (j < A) m = fmaxf(m, lg[j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j < A) sum += expf(lg[j] - m);
+    const float pa = expf(acc - m) / sum;               // (meaningful in the lanes a < A)
+    if (rv && a < A) {
+      probs_lds[row * A + a] = pa;
+      probs_out[row * A + a] = pa;
+    }
+    if (rv && a == A) values_out[row] = acc;
+    float pr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pr[j] = __shfl(pa, (lane & ~7) | j, 64);
+    if (rv && a < J) {
+      double remaining = 1.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (i < a) remaining -= (double)(pr[i] - 5.9604644775390625e-08f);
+      const double p = (double)(pa - 5.9604644775390625e-08f);
+      const double cond = p / remaining;
+      pj_buf[row * J + a] = cond;
+      if (cond == 0.0) *any_zero = 1;
+      if (thr_s) thr_s[row * J + a] = mt_pack_threshold(cond);
+    }
+  }
+};
+template <class H> struct HookFused { static constexpr bool value = false; };
+template <> struct HookFused<FusedHeadsHook> { static constexpr bool value = true; };
 template <int LDSC, class HOOK = NoProbsHook>
 __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, int N, int A,
                                                uint32_t* __restrict__ mt_state, double* __restrict__ pj_g,
@@ -536,6 +592,7 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
                                                const MtAhead* __restrict__ ahead = nullptr) {
   constexpr bool HOOKED = !__is_same(HOOK, NoProbsHook);
   constexpr bool OWNROWS = HookOwnRows<HOOK>::value;      // the hook finishes the heads of this workgroup's environments only
+  constexpr bool FUSED = HookFused<HOOK>::value;          // the hook does phase 1 too
   MISC_STAMP(0);
   constexpr bool LDSPATH = LDSC > 0;
   constexpr int PRW = LDSC == 2 ? 18 : 8;             // probability floats per thread of the one-round-trip load
@@ -693,10 +750,12 @@ __device__ __forceinline__ bool sample_mt_body(const float* __restrict__ probs, 
       probs_hook(probs_s, reinterpret_cast<float*>(jh_tab), p1_lo, p1_hi);
       for (int i = p1_lo * A + tid; i < p1_hi * A; i += 256)
         if ((pr[i] - 5.9604644775390625e-08f) == 0.0f) any_zero = 1;
+    } else if constexpr (FUSED) {
+      probs_hook(pj_buf, walk_ok ? thr_s : nullptr, &any_zero);
     } else {
       probs_hook();          // ends with a barrier: the probabilities are in LDS
     }
-    phase1(p1_lo, p1_hi);
+    if constexpr (!FUSED) phase1(p1_lo, p1_hi);
     __syncthreads();
   }
   MISC_STAMP(4);
@@ -1154,13 +1213,18 @@ __global__ __launch_bounds__(256) void synth_step_a_mth_kernel(const float* __re
     const uint32_t key0 = synth_key(seed, env_offset + (uint32_t)e0, id);
     const uint32_t hr5 = synth_reward_slot(key0);
     const bool term0 = synth_terminal(key0, thresh);
-    if (N * (A + 1) <= 256) {
-      // one (row, output) per thread: the partials are requested now and summed after the sampler's state blocks and
-      // doubles, which need nothing but the state words -- the loads travel while those phases compute
-      float pv[64], bias;      // (quarter-tile fc launches leave 64 partials per output at the stock fc width)
-      heads_partials_issue(partial, ntiles, N * (A + 1), A, ba, bc, pv, bias);
-      auto finish_heads = [&]() { heads_from_issued(pv, bias, partial, ntiles, N, A, lg_s, probs_sh, probs_out, values_out); };
-      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw, finish_heads,
+    if (N <= 32 && A <= 7 && ntiles <= 64) {
+      // (row = tid >> 3, output = tid & 7): the partials are requested now; summed, turned into probabilities and into
+      // conditional probabilities in registers after the sampler's state blocks and doubles (FusedHeadsHook)
+      float pv[64];
+      const int row = (int)threadIdx.x >> 3, a = (int)threadIdx.x & 7;
+      const int n = N * (A + 1);
+      const int idx = (row < N && a <= A) ? row * (A + 1) + a : 0;
+      const float bias = (a < A) ? ba[a] : bc[0];
+#pragma unroll
+      for (int t = 0; t < 64; ++t) pv[t] = partial[(size_t)(t < ntiles ? t : 0) * n + idx];
+      sample_mt_body<1>(nullptr, N, A, mt_state, nullptr, nullptr, nullptr, actions, act_s, probs_sh, stw,
+                        FusedHeadsHook{pv, bias, ntiles, N, A, probs_sh, probs_out, values_out},
                         MultiWalk{nullptr, nullptr, nullptr, 0}, ahead);
     } else {
       heads_from_partials(partial, ntiles, N, A, ba, bc, lg_s, probs_sh, nullptr, probs_out, values_out, nullptr, nullptr,

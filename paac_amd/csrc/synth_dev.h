@@ -76,15 +76,18 @@ __device__ __forceinline__ void synth_shift_band(uint64_t seed, uint32_t env_off
                                                  const bool force_reset = false) {
   const int e = unit / PRE_BANDS;
   const int band = unit % PRE_BANDS;
-  const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
-  const bool reset = force_reset || lowbias32(key ^ 0x3C6EF372u) < thresh;
   constexpr int QUADS_PER_BAND = OBS_PIX / PRE_BANDS / 4;  // 252: 12 rows of 21 quads
   const int i = threadIdx.x;
   if (i >= QUADS_PER_BAND) return;
   const int q = band * QUADS_PER_BAND + i;                 // = y * 21 + (x >> 2): the generator's word index
   const long quad = (long)e * (OBS_PIX / 4) + q;
-  uint4 old = make_uint4(0u, 0u, 0u, 0u);
-  if (!reset) old = reinterpret_cast<const uint4*>(stack_in)[quad];
+  // the old stack is requested whether or not this step resets the environment (1 step in 100 reads 16 bytes for nothing):
+  // the reset flag hangs on the step id, which the caller has just LOADED -- asked for only when needed, the two round
+  // trips to memory ran one after the other in every workgroup of the launch
+  uint4 old = force_reset ? make_uint4(0u, 0u, 0u, 0u) : reinterpret_cast<const uint4*>(stack_in)[quad];
+  const uint32_t key = synth_key(seed, env_offset + (uint32_t)e, id);
+  const bool reset = force_reset || lowbias32(key ^ 0x3C6EF372u) < thresh;
+  if (reset) old = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t w = synth_word(key, (uint32_t)q);
   const uint4 outv = make_uint4((old.x >> 8) | ((w & 255u) << 24), (old.y >> 8) | (((w >> 8) & 255u) << 24),
                                 (old.z >> 8) | (((w >> 16) & 255u) << 24), (old.w >> 8) | ((w >> 24) << 24));
