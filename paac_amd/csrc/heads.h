@@ -280,6 +280,45 @@ __device__ __forceinline__ void nstep_row_from(const ReturnsArgs& r, const int i
   y = (float)R;
   adv = (float)__dsub_rn(R, (double)r.values_act[(long)t * r.N + e]);
 }
+// The same scan with the row's rewards / masks / acting value already in registers (kNstepPre steps from the end of the
+// rollout; older steps, if the rollout is longer, are loaded here): the loads inside the loop are a chain of T round trips
+// to memory on the one thread that runs it.
+constexpr int kNstepPre = 8;
+struct NstepPre {
+  float rw[kNstepPre], mk[kNstepPre], vact;
+};
+__device__ __forceinline__ NstepPre nstep_preload(const ReturnsArgs& r, const int i) {
+  NstepPre p;
+  const int t = i / r.N, e = i - t * r.N;
+#pragma unroll
+  for (int k = 0; k < kNstepPre; ++k) {
+    const int tt = r.T - 1 - k;
+    const long at = (long)(tt >= t ? tt : t) * r.N + e;
+    p.rw[k] = r.rewards[at];
+    p.mk[k] = r.masks[at];
+  }
+  p.vact = r.values_act[(long)t * r.N + e];
+  return p;
+}
+__device__ __forceinline__ void nstep_row_from(const ReturnsArgs& r, const int i, const float vb, const NstepPre& p, float& y,
+                                               float& adv) {
+  const int t = i / r.N, e = i - t * r.N;
+  double R = 0.0;
+#pragma unroll
+  for (int k = 0; k < kNstepPre; ++k) {
+    const int tt = r.T - 1 - k;
+    if (tt >= t) {
+      const double prod = (k == 0) ? (double)__fmul_rn((float)r.gamma, vb) : __dmul_rn(r.gamma, R);
+      R = __dadd_rn((double)p.rw[k], __dmul_rn(prod, (double)p.mk[k]));
+    }
+  }
+  for (int tt = r.T - 1 - kNstepPre; tt >= t; --tt) {
+    const long k = (long)tt * r.N + e;
+    R = __dadd_rn((double)r.rewards[k], __dmul_rn(__dmul_rn(r.gamma, R), (double)r.masks[k]));
+  }
+  y = (float)R;
+  adv = (float)__dsub_rn(R, (double)p.vact);
+}
 __device__ __forceinline__ void nstep_row(const ReturnsArgs& r, const int i, float& y, float& adv) {
   nstep_row_from(r, i, r.v_boot[i % r.N], y, adv);
 }
@@ -499,6 +538,9 @@ __global__ __launch_bounds__(256) void heads_train_kernel(const float* __restric
     for (int a = 0; a < AP; ++a) waj[jj][a] = Wa[j * A + (a < A ? a : 0)];
   }
   const int act = actions[i];
+  // (the row's n-step scan runs on thread 0 further down: its inputs are wave-uniform addresses, requested here)
+  NstepPre npre;
+  if (rt.rewards) npre = nstep_preload(rt, i);
   float part[NB], hv[JPT];
 #pragma unroll
   for (int a = 0; a < NB; ++a) part[a] = 0.f;
@@ -549,7 +591,7 @@ __global__ __launch_bounds__(256) void heads_train_kernel(const float* __restric
     values_ws[i] = lg[AP];
     float yv, av;
     if (rt.rewards) {
-      nstep_row_from(rt, i, boot ? lg[NV] : rt.v_boot[i % rt.N], yv, av);
+      nstep_row_from(rt, i, boot ? lg[NV] : rt.v_boot[i % rt.N], npre, yv, av);
       rt.y_out[i] = yv;                      // the learner's records of the returns (paac.py:151-154 feed layout)
       rt.adv_out[i] = av;
       if (boot && i < rt.N) values_ws[B + i] = lg[NV];
