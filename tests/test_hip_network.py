@@ -137,6 +137,44 @@ def test_managed_acting_forward_parity(A, B, scale):
     ctx.close()
 
 
+@pytest.mark.parametrize("managed", [True, False])
+@pytest.mark.parametrize("arch,A,B,scale", [("NATURE", 4, 32, 1.0), ("NATURE", 4, 32, SATURATED), ("NATURE", 6, 1, 1.0),
+                                            ("NATURE", 18, 7, 1.0), ("NATURE", 4, 9, TRAINED), ("NATURE", 6, 24, 1.0),
+                                            ("NIPS", 6, 32, 1.0), ("NIPS", 4, 57, TRAINED), ("NIPS", 6, 64, 1.0)])
+def test_fc_quarter_tiles(arch, A, B, scale, managed, monkeypatch):
+    """csrc/fc_heads.h: fc_heads_q_kernel (8 rows x 8 fc columns per workgroup, the even and the odd K groups of a pair riding
+    in the two diagonal blocks of one MFMA; up to 32 rows of the stock widths, 64 for NIPS) against the float64 oracle and
+    against the whole-tile kernel (PAAC_FC_QUARTER=0): the same sums in another order, ragged row counts included, from the
+    tower's fragment-order hand-off (managed) and from plain rows."""
+    from paac_amd import hip_ops
+    params, states, idx, y, adv = make_case(arch, A, B, seed=9, weight_scale=scale)
+    ref = onet.forward(params, states, arch, dtype=np.float64)
+    out = []
+    for quarter in ("1", "0"):
+        monkeypatch.setenv("PAAC_FC_QUARTER", quarter)          # read when the context is created
+        ctx = hip_ops.Context(ARCH_ID[arch], A, max_batch=B)
+        p = upload_params(ctx, params)
+        if managed:
+            ctx.set_managed_weights(True)
+            ctx.pack_weights(p)
+        s = torch.from_numpy(states).cuda()
+        logits, probs, values = torch.zeros((B, A), device="cuda"), torch.zeros((B, A), device="cuda"), torch.zeros(B, device="cuda")
+        ctx.prof_enable(True)
+        ctx.forward(p, s, logits, probs, values)
+        torch.cuda.synchronize()
+        assert ("fc_fwd", B) in {(n, b) for n, b, _ in ctx.prof_read()}
+        ctx.prof_enable(False)
+        out.append((logits.cpu().numpy(), values.cpu().numpy(), probs.cpu().numpy()))
+        ctx.close()
+    for lg, v, pr in out:
+        assert np.abs(lg - ref["logits"]).max() < 1e-4 and np.abs(v - ref["v"]).max() < 1e-4
+        assert np.abs(pr - ref["pi"]).max() < 1e-5
+    tol = 2e-5 * max(1.0, np.abs(ref["logits"]).max())
+    assert np.abs(out[0][0] - out[1][0]).max() < tol and np.abs(out[0][1] - out[1][1]).max() < tol
+    if scale == 1.0:
+        assert not np.array_equal(out[0][0], out[1][0])      # two different kernels did run (another summation order)
+
+
 @pytest.mark.parametrize("arch,A,B", [("NATURE", 4, 160), ("NATURE", 6, 40), ("NATURE", 18, 9), ("NIPS", 6, 40),
                                       ("NIPS", 4, 160), ("NATURE", 4, 320),
                                       ("NATURE", 4, 1280),     # 256 envs x t_max 5 (BASELINE configs[2]): heuristics
