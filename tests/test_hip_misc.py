@@ -259,6 +259,9 @@ def test_synthetic_env_matches_host_spec(raw_frames):
 
 @pytest.mark.parametrize("managed", [False, True])
 @pytest.mark.parametrize("arch,A,N", [("NATURE", 4, 32), ("NATURE", 6, 33), ("NIPS", 18, 16), ("NATURE", 18, 60),
+                                      # the sampler workgroup finishes the heads in registers up to 32 environments x 7 actions
+                                      # (misc.hip: FusedHeadsHook): its corners
+                                      ("NATURE", 7, 32), ("NIPS", 2, 5), ("NATURE", 6, 17), ("NATURE", 8, 28),
                                       # the large shards (four launches; managed: the sampler's MT19937 doubles come from the
                                       # spare workgroup of the fc launch, csrc/mt_ahead.h): configs[4] and configs[2] per GPU
                                       ("NATURE", 18, 128), ("NATURE", 4, 256), ("NATURE", 9, 100)])
