@@ -182,12 +182,14 @@ static void launch_tower(paac_ctx* ctx, Workspace& W, const float* params, const
 #ifdef PAAC_DMM_STAMPS
   a.stamps = g_tower_stamps;
 #endif
-  // regions per sample: as many as keep the launch within about one round of the 256 CUs
+  // regions per sample: as many as keep the launch within ONE round of the 256 CUs (a workgroup takes a CU's LDS: workgroup
+  // 257 waits for the first to finish -- tools/probe_regions.py: 68 rows as 4 regions = 272 workgroups 30.5 us per forward
+  // against 25.3 as 2 regions, 136 rows as 2 regions 42.2 against 35.7 as 1)
   const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
   // (every workgroup streams all the weights, so more regions is more L2 traffic: at 32 rows 8 regions of 4x2 -- 256
   // workgroups -- take 11.0 us as a launch of their own against 10.7 for 4 of 4x4, but the replayed cycle is 2 us shorter
   // with them, 653 k against 648 k env-steps/s in two A/B pairs: the launch ramps and drains faster on all 256 CUs)
-  int regions = (8 * batch <= 256) ? 8 : (4 * batch <= 288) ? 4 : (2 * batch <= 288) ? 2 : 1;
+  int regions = (8 * batch <= 256) ? 8 : (4 * batch <= 256) ? 4 : (2 * batch <= 256) ? 2 : 1;
   if (force == 1 || force == 2 || force == 4 || force == 8) regions = force;
   if (regions == 8) {
     if (keep) launch_tower_variant<TowerGeom<4, 2>, true>(a, s);
@@ -232,8 +234,9 @@ static void launch_tower2(paac_ctx* ctx, Workspace& W, const float* params, cons
     else a.act2 = keepW->act[1] + (size_t)keep_row * kT2Flat;
   }
   const int force = ctx->tune[OP_CONV_TOWER][batch_class(batch)].cfg;
-  // regions per sample: nine 3x3 regions while that stays near one round of the 256 CUs, four 5x5 up to 72 rows, else one
-  int regions = (9 * batch <= 320) ? 9 : (4 * batch <= 288) ? 4 : 1;
+  // regions per sample: nine 3x3 regions while that stays within one round of the 256 CUs (28 rows), four 5x5 up to 64 rows,
+  // else one (tools/probe_regions.py: at 32 rows nine regions = 288 workgroups 17.0 us per forward against 14.2 with four)
+  int regions = (9 * batch <= 256) ? 9 : (4 * batch <= 256) ? 4 : 1;
   if (force == 1 || force == 4 || force == 9) regions = force;
   if (regions == 9) {
     if (keep) launch_tower2_variant<Tower2Geom<3, 3>, true>(a, s);
